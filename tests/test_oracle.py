@@ -1,0 +1,108 @@
+"""Pin the oracle (oracle/) against the reference's own fixtures and golden vectors (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features as ofeat
+from oracle import pace_oracle as po
+from tests.helpers import CONFIGS, grad_err, graphs_from, load_golden, load_npz, rel
+
+
+def test_pace_wrapping_fixture():
+    # reference fixture tests/models/test_pace_utils.py:18-61
+    labels = [0, 1, 2, 3, 4]
+    edges = [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4)]
+    pl, pe, pos = ofeat.pace_wrap(labels, edges)
+    assert pl == [2, 0, 3, 4, 5, 6, 7, 1]
+    assert sorted(pe) == sorted([(0, 1), (1, 2), (2, 3), (2, 4), (3, 4), (4, 5), (5, 6), (6, 7)])
+    assert pos == list(range(8))
+
+
+def test_row_codec_fixture():
+    # reference fixture tests/toolkit/test_labeled.py:49-64 (pydict) <-> edges
+    row = {"l0": 0, "l1": 1, "l2": 2, "l3": 3, "l4": 4,
+           "e0": "", "e1": "1", "e2": "11", "e3": "001", "e4": "0001"}
+    labels, edges = ofeat.row_to_labeled(row, 5)
+    assert labels == [0, 1, 2, 3, 4]
+    assert edges == [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4)]
+    assert ofeat.labeled_to_row(labels, edges) == row
+    with pytest.raises(ValueError):
+        ofeat.row_to_labeled({**row, "e3": "01"}, 5)
+
+
+def test_topological_order_quirk():
+    # a graph whose FIFO-Kahn order is not the identity; positions[v] = order[v] (pace.py:1286)
+    labels = [0, 0, 0, 0]
+    edges = [(0, 3), (1, 2)]          # user vertices 0,1 are sources; 2,3 sinks
+    pl, pe, pos = ofeat.pace_wrap(labels, edges)
+    order = ofeat.topological_order_fifo(7, pe)
+    assert pos == order
+    assert order[:4] == [0, 1, 2, 3] and sorted(order) == list(range(7))
+
+
+def test_known_answer_mu():
+    """1408-row known answer (subset): test parquet graph -> mu under ckpt 110, as written by the
+    reference's prepare_predictor_data (experiments/01_bn_asia/main.py:268-303)."""
+    z = load_npz("asia_known_answer.npz")
+    ck = load_npz("asia_ckpt110.npz")
+    params = {k: torch.from_numpy(ck[k]).float() for k in ck.files}
+    cfg = po.PaceConfig(n=8, card=8)
+    graphs = graphs_from(z, 8)
+    f = ofeat.to_torch(ofeat.dense_features(graphs, 8))
+    with torch.no_grad():
+        mu, _ = po.encode_direct(params, cfg, f)
+    assert np.abs(mu.numpy() - z["mu"]).max() < 5e-6
+    nonid = sum(ofeat.pace_wrap(*g)[2] != list(range(11)) for g in graphs)
+    assert nonid >= 32     # the fixture exercises the order quirk
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oracle_matches_reference_eval(name):
+    cfg, params, graphs, z = load_golden(name)
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = ofeat.to_torch(ofeat.dense_features(graphs, cfg.card))
+    total, recon, kld, aux = po.loss_direct(P, cfg, f, training=False, return_aux=True)
+    assert rel(total, z["eval/total"]) < 1e-5
+    assert rel(kld, z["eval/kld"]) < 1e-5
+    assert abs(float(recon.detach()) - float(z["eval/recon"])) < 1e-5 * max(1.0, abs(float(z["eval/recon"])))
+    assert np.abs(aux["mu"].detach().numpy() - z["eval/mu"]).max() < 1e-5
+    assert np.abs(aux["logvar"].detach().numpy() - z["eval/logvar"]).max() < 1e-5
+    assert np.abs(aux["decoder_output"].detach().numpy() - z["eval/decoder_output"]).max() < 1e-4
+    total.backward()
+    err, worst = grad_err({k: v.grad for k, v in P.items()}, z, "eval/grad/")
+    assert err < 1e-3, worst
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oracle_matches_reference_train0_and_step(name):
+    cfg, params, graphs, z = load_golden(name)
+    cfg0 = po.PaceConfig(n=cfg.n, card=cfg.card, dropout=0.0)
+    f = ofeat.to_torch(ofeat.dense_features(graphs, cfg.card))
+    tr = po.OracleTrainer(cfg0, params)
+    value, recon, kld = tr.step(f, training=True, eps=torch.from_numpy(z["train0/eps"]))
+    assert rel(value, z["train0/total"]) < 1e-5
+    assert rel(kld, z["train0/kld"]) < 1e-5
+    # First Adam step moves each weight by lr*g/(|g|+1e-8): well-conditioned only where the clipped
+    # gradient is >> 1e-8, so compare tightly there and loosely (a fraction of one lr step) elsewhere.
+    gn = np.sqrt(sum(float((z[k].astype(np.float64) ** 2).sum()) for k in z.files if k.startswith("train0/grad/")))
+    coef = min(1.0, 1.0 / (gn + 1e-6))
+    worst_big, worst_all = 0.0, 0.0
+    for k in z.files:
+        if k.startswith("step/param/"):
+            n = k[len("step/param/"):]
+            err = np.abs(tr.P[n].detach().numpy() - z[k])
+            big = np.abs(z["train0/grad/" + n]) * coef > 1e-5
+            worst_all = max(worst_all, float(err.max()))
+            if big.any():
+                worst_big = max(worst_big, float(err[big].max()))
+    assert worst_big < 1e-6 and worst_all < 3e-5
+
+
+def test_synthetic_dags_are_valid():
+    gs = ofeat.synthetic_dags(12, 12, 64, seed=3)
+    assert len(gs) == 64
+    for labels, edges in gs:
+        assert sorted(labels) == list(range(12))
+        assert all(u < v for u, v in edges) and 11 <= len(edges) <= 26
+    gs1 = ofeat.synthetic_dags(12, 1, 8, seed=3)
+    assert all(l == [0] * 12 for l, _ in gs1)

@@ -1,0 +1,109 @@
+"""ctypes binding of libdvs_hip.so (C ABI: include/dvs.h).
+
+The product has exactly one compute path: the HIP library.  ``load()`` raises if it is missing — there is
+no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libdvs_hip.so"
+
+D_MODEL, HEADS, LAYERS, LATENT, FC_HIDDEN, EMB = 64, 8, 3, 32, 32, 32
+MAX_TOKENS = 16
+RECORD_BYTES = 96
+
+
+class DvsShape(Structure):
+    _fields_ = [("batch", c_int32), ("n_tokens", c_int32), ("n_classes", c_int32), ("training", c_int32),
+                ("dropout", c_float), ("beta", c_float), ("eps_scale", c_float), ("dag_offset", c_uint32),
+                ("seed", c_uint64)]
+
+
+class DvsParamEntry(Structure):
+    _fields_ = [("name", c_char * 64), ("offset", c_int64), ("rows", c_int32), ("cols", c_int32)]
+
+
+def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    """Declare argument/return types of every entry point of include/dvs.h on a loaded library."""
+    P = POINTER
+    lib.dvs_version.restype = c_int
+    lib.dvs_last_error.restype = c_char_p
+    lib.dvs_device_cus.restype = c_int
+    lib.dvs_param_count.restype = c_int64
+    lib.dvs_param_count.argtypes = [P(DvsShape)]
+    lib.dvs_param_table.restype = c_int
+    lib.dvs_param_table.argtypes = [P(DvsShape), P(DvsParamEntry), c_int]
+    lib.dvs_workspace_bytes.restype = c_size_t
+    lib.dvs_workspace_bytes.argtypes = [P(DvsShape)]
+    lib.dvs_pack_features.restype = c_int
+    lib.dvs_pack_features.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_loss_forward.restype = c_int
+    lib.dvs_loss_forward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]
+    lib.dvs_loss_backward.restype = c_int
+    lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_encode.restype = c_int
+    lib.dvs_encode.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_clip_adam.restype = c_int
+    lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                                  c_int64, c_float, c_void_p, c_void_p]
+    lib.dvs_debug_activation.restype = c_int
+    lib.dvs_debug_activation.argtypes = [P(DvsShape), c_void_p, c_int, c_void_p, c_void_p]
+    return lib
+
+
+EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
+           "dvs_workspace_bytes", "dvs_pack_features", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
+           "dvs_clip_adam", "dvs_debug_activation"]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree HIP library (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{LIB_NAME} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(hipcc --offload-arch=gfx950).  dags_vae_search_amd has no CPU fallback.")
+        _lib = bind(ctypes.CDLL(path))
+        if _lib.dvs_version() != 100:
+            raise RuntimeError(f"{LIB_NAME}: unexpected ABI version {_lib.dvs_version()}")
+    return _lib
+
+
+def check(lib, code: int, what: str):
+    if code != 0:
+        msg = lib.dvs_last_error()
+        raise RuntimeError(f"{what} failed with code {code}: {msg.decode() if msg else ''}")
+
+
+def make_shape(batch: int, n_tokens: int, n_classes: int, training: bool = False, dropout: float = 0.15,
+               beta: float = 0.005, eps_scale: float = 0.01, dag_offset: int = 0, seed: int = 0) -> DvsShape:
+    return DvsShape(int(batch), int(n_tokens), int(n_classes), 1 if training else 0, float(dropout), float(beta),
+                    float(eps_scale), int(dag_offset) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+def param_table(lib, shape: DvsShape):
+    """[(name, offset, shape tuple)] of the 108 state-dict tensors inside the flat buffer, and its length."""
+    entries = (DvsParamEntry * 128)()
+    n = lib.dvs_param_table(ctypes.byref(shape), entries, 128)
+    if n <= 0:
+        check(lib, 1, "dvs_param_table")
+    table = []
+    for e in entries[:n]:
+        shp = (e.rows, e.cols) if e.cols else (e.rows,)
+        table.append((e.name.decode(), int(e.offset), shp))
+    total = int(lib.dvs_param_count(ctypes.byref(shape)))
+    return table, total

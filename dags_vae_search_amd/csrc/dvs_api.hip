@@ -1,0 +1,489 @@
+// C ABI (include/dvs.h): parameter/workspace layout and the launch sequences of the PACE-VAE step.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dvs_kernels.h"
+#include "dvs_backward.h"
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+extern "C" int dvs_version(void) { return DVS_VERSION; }
+extern "C" const char* dvs_last_error(void) { return g_err; }
+
+extern "C" int dvs_device_cus(void) {
+#ifdef DVS_EMU
+    return 2;
+#else
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+#endif
+}
+
+// ---- flat parameter layout ---------------------------------------------------------------------------------
+namespace {
+struct LayoutBuilder {
+    int64_t off = 0;
+    dvs_param_entry* table;
+    int cap, count = 0;
+    int64_t add(const char* name, int rows, int cols) {
+        const int64_t o = off;
+        if (table && count < cap) {
+            dvs_param_entry& e = table[count];
+            memset(&e, 0, sizeof(e));
+            snprintf(e.name, sizeof(e.name), "%s", name);
+            e.offset = o;
+            e.rows = rows;
+            e.cols = cols;
+        }
+        ++count;
+        const int64_t n = (int64_t)rows * (cols ? cols : 1);
+        off += (n + 3) & ~(int64_t)3;
+        return o;
+    }
+};
+}  // namespace
+
+DvsLayout dvs_make_layout(int N, int C, dvs_param_entry* table, int cap, int* count) {
+    LayoutBuilder b;
+    b.table = table;
+    b.cap = cap;
+    DvsLayout l;
+    char nm[96];
+    auto attn = [&](const char* prefix, DvsAttnP& p) {
+        snprintf(nm, sizeof(nm), "%s.in_proj_weight", prefix);  p.in_w = b.add(nm, 192, 64);
+        snprintf(nm, sizeof(nm), "%s.in_proj_bias", prefix);    p.in_b = b.add(nm, 192, 0);
+        snprintf(nm, sizeof(nm), "%s.out_proj.weight", prefix); p.out_w = b.add(nm, 64, 64);
+        snprintf(nm, sizeof(nm), "%s.out_proj.bias", prefix);   p.out_b = b.add(nm, 64, 0);
+    };
+    auto ffn = [&](const char* prefix, DvsFfnP& p) {
+        snprintf(nm, sizeof(nm), "%s.linear1.weight", prefix); p.l1_w = b.add(nm, 64, 64);
+        snprintf(nm, sizeof(nm), "%s.linear1.bias", prefix);   p.l1_b = b.add(nm, 64, 0);
+        snprintf(nm, sizeof(nm), "%s.linear2.weight", prefix); p.l2_w = b.add(nm, 64, 64);
+        snprintf(nm, sizeof(nm), "%s.linear2.bias", prefix);   p.l2_b = b.add(nm, 64, 0);
+    };
+    auto norm = [&](const char* prefix, int k, DvsNormP& p) {
+        snprintf(nm, sizeof(nm), "%s.norm%d.weight", prefix, k); p.w = b.add(nm, 64, 0);
+        snprintf(nm, sizeof(nm), "%s.norm%d.bias", prefix, k);   p.b = b.add(nm, 64, 0);
+    };
+    l.W1 = b.add("vertex_position_embed.W1", 2 * N, 64);
+    l.W2 = b.add("vertex_position_embed.W2", 64, 32);
+    l.lab_w = b.add("vertex_label_embed.0.weight", 32, C);
+    l.lab_b = b.add("vertex_label_embed.0.bias", 32, 0);
+    char pre[64], pre2[80];
+    for (int i = 0; i < DVS_LAYERS; ++i) {
+        snprintf(pre, sizeof(pre), "encoder.layers.%d", i);
+        snprintf(pre2, sizeof(pre2), "%s.self_attn", pre);
+        attn(pre2, l.enc[i].sa);
+        ffn(pre, l.enc[i].ff);
+        norm(pre, 1, l.enc[i].n1);
+        norm(pre, 2, l.enc[i].n2);
+    }
+    l.fc1_w = b.add("fc1.weight", 32, N * 64);
+    l.fc1_b = b.add("fc1.bias", 32, 0);
+    l.fc2_w = b.add("fc2.weight", 32, N * 64);
+    l.fc2_b = b.add("fc2.bias", 32, 0);
+    for (int i = 0; i < DVS_LAYERS; ++i) {
+        snprintf(pre, sizeof(pre), "decoder.layers.%d", i);
+        snprintf(pre2, sizeof(pre2), "%s.self_attn", pre);
+        attn(pre2, l.dec[i].sa);
+        snprintf(pre2, sizeof(pre2), "%s.multihead_attn", pre);
+        attn(pre2, l.dec[i].ca);
+        ffn(pre, l.dec[i].ff);
+        norm(pre, 1, l.dec[i].n1);
+        norm(pre, 2, l.dec[i].n2);
+        norm(pre, 3, l.dec[i].n3);
+    }
+    l.node0_w = b.add("add_node.0.weight", 32, 64);
+    l.node0_b = b.add("add_node.0.bias", 32, 0);
+    l.node2_w = b.add("add_node.2.weight", C, 32);
+    l.node2_b = b.add("add_node.2.bias", C, 0);
+    l.edge0_w = b.add("add_edge.0.weight", 64, 128);
+    l.edge0_b = b.add("add_edge.0.bias", 64, 0);
+    l.edge2_w = b.add("add_edge.2.weight", 1, 64);
+    l.edge2_b = b.add("add_edge.2.bias", 1, 0);
+    l.fc3_w = b.add("fc3.weight", N * 64, 32);
+    l.fc3_b = b.add("fc3.bias", N * 64, 0);
+    l.total = b.off;
+    if (count) *count = b.count;
+    return l;
+}
+
+DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab) {
+    DvsWorkspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        const size_t o = off;
+        off += (n + 63) & ~(size_t)63;
+        return o;
+    };
+    const size_t tile = (size_t)B * 1024;
+    for (int s = 0; s < DVS_NSLOTS; ++s) {
+        w.act[s] = take(tile);
+        w.stats[s] = take((size_t)B * 32);
+    }
+    w.enc_out = take(tile);
+    w.mu = take((size_t)B * 32);
+    w.logvar = take((size_t)B * 32);
+    w.z = take((size_t)B * 32);
+    w.epsv = take((size_t)B * 32);
+    w.mem = take(tile);
+    w.dag_loss = take((size_t)B * 2);
+    w.gA = take(tile);
+    w.gB = take(tile);
+    w.gq = take(tile);
+    w.gk = take(tile);
+    w.gv = take(tile);
+    w.gmem = take(tile);
+    w.genc = take(tile);
+    w.gz = take((size_t)B * 64);
+    w.nslab = nslab;
+    w.slabs = take((size_t)nslab * (size_t)P);
+    w.total_floats = off;
+    return w;
+}
+
+// ---- shape checks / derived dims ------------------------------------------------------------------------------
+static int check_shape(const dvs_shape* s) {
+    if (!s) return fail(1, "dvs: null shape");
+    if (s->batch <= 0) return fail(2, "dvs: batch must be > 0");
+    if (s->n_tokens < 4 || s->n_tokens > DVS_MAXTOK)
+        return fail(3, "dvs: n_tokens (= max_num_vertices + 3) must be in [4, 16] in this build");
+    if (s->n_classes < 4 || s->n_classes > 16)
+        return fail(4, "dvs: n_classes (= vertex_label_cardinality + 3) must be in [4, 16] in this build");
+    if (!(s->dropout >= 0.f && s->dropout < 1.f)) return fail(5, "dvs: dropout must be in [0, 1)");
+    return 0;
+}
+
+static DvsDims make_dims(const dvs_shape* s) {
+    DvsDims d;
+    d.B = s->batch;
+    d.N = s->n_tokens;
+    d.C = s->n_classes;
+    d.training = s->training ? 1 : 0;
+    d.drop.thr16 = (uint32_t)lrintf(s->dropout * 65536.0f);
+    d.drop.on = (d.training && d.drop.thr16 > 0) ? 1 : 0;
+    d.drop.scale = 1.0f / (1.0f - (float)d.drop.thr16 / 65536.0f);
+    d.seed_lo = (uint32_t)(s->seed & 0xFFFFFFFFull);
+    d.seed_hi = (uint32_t)(s->seed >> 32);
+    d.dag_offset = s->dag_offset;
+    d.beta = s->beta;
+    d.eps_scale = s->eps_scale;
+    return d;
+}
+
+static int grid_for(int B) {
+    const int cus = dvs_device_cus();
+    const int want = (B + 3) / 4;
+    const int cap = cus > 0 ? cus : 256;
+    return want < cap ? want : cap;
+}
+
+int dvs_num_slabs() {   // backward kernels run on exactly this many workgroups (one gradient slab each)
+    const int cus = dvs_device_cus();
+    return cus > 0 ? cus : 256;
+}
+
+extern "C" int64_t dvs_param_count(const dvs_shape* s) {
+    if (check_shape(s)) return -1;
+    return dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
+}
+
+extern "C" int dvs_param_table(const dvs_shape* s, dvs_param_entry* out, int cap) {
+    if (check_shape(s)) return -1;
+    int count = 0;
+    dvs_make_layout(s->n_tokens, s->n_classes, out, cap, &count);
+    return count;
+}
+
+extern "C" size_t dvs_workspace_bytes(const dvs_shape* s) {
+    if (check_shape(s)) return 0;
+    const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
+    return dvs_make_workspace(s->batch, P, dvs_num_slabs()).total_floats * sizeof(float);
+}
+
+extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
+                                 const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
+                                 void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!label_onehot || !pos_onehot || !adjacency || !target_masks || !records || !status)
+        return fail(10, "dvs_pack_features: null pointer");
+    PackArgs a;
+    a.B = s->batch;
+    a.N = s->n_tokens;
+    a.C = s->n_classes;
+    a.lab1h = label_onehot;
+    a.pos1h = pos_onehot;
+    a.adj = adjacency;
+    a.tmask = target_masks;
+    a.rec = (DvsRecord*)records;
+    a.status = status;
+    dvs_launch_pack(a, (dvs_stream_t)stream);
+    return 0;
+}
+
+// slot numbering of saved activations
+static inline int slot_enc(int layer, int sub) { return 1 + 2 * layer + sub; }        // sub 0 attn, 1 ffn
+static inline int slot_dec(int layer, int sub) { return 8 + 3 * layer + sub; }        // sub 0 self, 1 cross, 2 ffn
+// dropout sites (34 per step): 0,1 enc-embed; 2,3 dec-embed; 4+4l+{0..3} encoder; 16+6l+{0..5} decoder
+static inline int site_enc(int layer, int k) { return 4 + 4 * layer + k; }
+static inline int site_dec(int layer, int k) { return 16 + 6 * layer + k; }
+
+static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
+                            const float* P, float* ws, int grid, dvs_stream_t st) {
+    EmbedArgs e;
+    memset(&e, 0, sizeof(e));
+    e.dims = d;
+    e.rec = rec;
+    e.W1 = P + L.W1;
+    e.W2 = P + L.W2;
+    e.lab_w = P + L.lab_w;
+    e.lab_b = P + L.lab_b;
+    e.out = ws + W.act[0];
+    e.site = 0;
+    dvs_launch_embed_fwd(e, grid, st);
+    DvsLN ln = {nullptr, nullptr, nullptr};
+    int prev = 0;
+    for (int i = 0; i < DVS_LAYERS; ++i) {
+        AttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dims = d;
+        a.rec = rec;
+        a.xin = ws + W.act[prev];
+        a.ln = ln;
+        a.kv = nullptr;
+        a.in_w = P + L.enc[i].sa.in_w;
+        a.in_b = P + L.enc[i].sa.in_b;
+        a.out_w = P + L.enc[i].sa.out_w;
+        a.out_b = P + L.enc[i].sa.out_b;
+        const int sa = slot_enc(i, 0);
+        a.out_pre = ws + W.act[sa];
+        a.out_stats = ws + W.stats[sa];
+        a.site_prob = site_enc(i, 0);
+        a.site_post = site_enc(i, 1);
+        dvs_launch_attn_fwd(a, grid, st);
+        FfnArgs f;
+        memset(&f, 0, sizeof(f));
+        f.dims = d;
+        f.xin = ws + W.act[sa];
+        f.ln = DvsLN{ws + W.stats[sa], P + L.enc[i].n1.w, P + L.enc[i].n1.b};
+        f.l1_w = P + L.enc[i].ff.l1_w;
+        f.l1_b = P + L.enc[i].ff.l1_b;
+        f.l2_w = P + L.enc[i].ff.l2_w;
+        f.l2_b = P + L.enc[i].ff.l2_b;
+        const int sf = slot_enc(i, 1);
+        f.out_pre = ws + W.act[sf];
+        f.out_stats = ws + W.stats[sf];
+        f.site_hidden = site_enc(i, 2);
+        f.site_post = site_enc(i, 3);
+        if (i == DVS_LAYERS - 1) {
+            f.out_norm = ws + W.enc_out;
+            f.ng = P + L.enc[i].n2.w;
+            f.nb = P + L.enc[i].n2.b;
+        }
+        dvs_launch_ffn_fwd(f, grid, st);
+        ln = DvsLN{ws + W.stats[sf], P + L.enc[i].n2.w, P + L.enc[i].n2.b};
+        prev = sf;
+    }
+}
+
+static LatentArgs latent_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const float* P, float* ws,
+                              const float* eps, bool with_mem) {
+    LatentArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dims = d;
+    a.xenc = ws + W.enc_out;
+    a.fc1_w = P + L.fc1_w;
+    a.fc1_b = P + L.fc1_b;
+    a.fc2_w = P + L.fc2_w;
+    a.fc2_b = P + L.fc2_b;
+    a.fc3_w = P + L.fc3_w;
+    a.fc3_b = P + L.fc3_b;
+    a.eps_in = eps;
+    a.mu = ws + W.mu;
+    a.logvar = ws + W.logvar;
+    a.z = ws + W.z;
+    a.epsv = ws + W.epsv;
+    a.mem = with_mem ? ws + W.mem : nullptr;
+    a.dag_loss = ws + W.dag_loss;
+    return a;
+}
+
+LossArgs dvs_loss_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec, const float* P,
+                       float* ws) {
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dims = d;
+    a.rec = rec;
+    const int last = slot_dec(DVS_LAYERS - 1, 2);
+    a.xin = ws + W.act[last];
+    a.ln = DvsLN{ws + W.stats[last], P + L.dec[DVS_LAYERS - 1].n3.w, P + L.dec[DVS_LAYERS - 1].n3.b};
+    a.node0_w = P + L.node0_w;
+    a.node0_b = P + L.node0_b;
+    a.node2_w = P + L.node2_w;
+    a.node2_b = P + L.node2_b;
+    a.edge0_w = P + L.edge0_w;
+    a.edge0_b = P + L.edge0_b;
+    a.edge2_w = P + L.edge2_w;
+    a.edge2_b = P + L.edge2_b;
+    a.dag_loss = ws + W.dag_loss;
+    return a;
+}
+
+extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
+                                const float* eps, float* losses, float* mu, float* logvar, void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
+    const DvsDims d = make_dims(s);
+    const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
+    const DvsWorkspace W = dvs_make_workspace(d.B, L.total, dvs_num_slabs());
+    float* ws = (float*)workspace;
+    const DvsRecord* rec = (const DvsRecord*)records;
+    dvs_stream_t st = (dvs_stream_t)stream;
+    const int grid = grid_for(d.B);
+
+    encoder_forward(d, L, W, rec, params, ws, grid, st);
+    dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
+
+    // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
+    // only to redraw the dropout masks)
+    int dec_in = 0;
+    if (d.drop.on) {
+        EmbedArgs e;
+        memset(&e, 0, sizeof(e));
+        e.dims = d;
+        e.rec = rec;
+        e.W1 = params + L.W1;
+        e.W2 = params + L.W2;
+        e.lab_w = params + L.lab_w;
+        e.lab_b = params + L.lab_b;
+        e.out = ws + W.act[7];
+        e.site = 2;
+        dvs_launch_embed_fwd(e, grid, st);
+        dec_in = 7;
+    }
+    DvsLN ln = {nullptr, nullptr, nullptr};
+    int prev = dec_in;
+    for (int i = 0; i < DVS_LAYERS; ++i) {
+        const auto& pl = L.dec[i];
+        AttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dims = d;
+        a.rec = rec;
+        a.xin = ws + W.act[prev];
+        a.ln = ln;
+        a.in_w = params + pl.sa.in_w;
+        a.in_b = params + pl.sa.in_b;
+        a.out_w = params + pl.sa.out_w;
+        a.out_b = params + pl.sa.out_b;
+        const int s0 = slot_dec(i, 0);
+        a.out_pre = ws + W.act[s0];
+        a.out_stats = ws + W.stats[s0];
+        a.site_prob = site_dec(i, 0);
+        a.site_post = site_dec(i, 1);
+        dvs_launch_attn_fwd(a, grid, st);
+
+        AttnArgs c;
+        memset(&c, 0, sizeof(c));
+        c.dims = d;
+        c.rec = rec;
+        c.xin = ws + W.act[s0];
+        c.ln = DvsLN{ws + W.stats[s0], params + pl.n1.w, params + pl.n1.b};
+        c.kv = ws + W.mem;
+        c.in_w = params + pl.ca.in_w;
+        c.in_b = params + pl.ca.in_b;
+        c.out_w = params + pl.ca.out_w;
+        c.out_b = params + pl.ca.out_b;
+        const int s1 = slot_dec(i, 1);
+        c.out_pre = ws + W.act[s1];
+        c.out_stats = ws + W.stats[s1];
+        c.site_prob = site_dec(i, 2);
+        c.site_post = site_dec(i, 3);
+        dvs_launch_attn_fwd(c, grid, st);
+
+        FfnArgs f;
+        memset(&f, 0, sizeof(f));
+        f.dims = d;
+        f.xin = ws + W.act[s1];
+        f.ln = DvsLN{ws + W.stats[s1], params + pl.n2.w, params + pl.n2.b};
+        f.l1_w = params + pl.ff.l1_w;
+        f.l1_b = params + pl.ff.l1_b;
+        f.l2_w = params + pl.ff.l2_w;
+        f.l2_b = params + pl.ff.l2_b;
+        const int s2 = slot_dec(i, 2);
+        f.out_pre = ws + W.act[s2];
+        f.out_stats = ws + W.stats[s2];
+        f.site_hidden = site_dec(i, 4);
+        f.site_post = site_dec(i, 5);
+        dvs_launch_ffn_fwd(f, grid, st);
+        ln = DvsLN{ws + W.stats[s2], params + pl.n3.w, params + pl.n3.b};
+        prev = s2;
+    }
+    dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid, st);
+    FinalizeArgs fa;
+    fa.B = d.B;
+    fa.beta = d.beta;
+    fa.dag_loss = ws + W.dag_loss;
+    fa.losses = losses;
+    dvs_launch_finalize(fa, st);
+    const size_t nb = (size_t)d.B * 32 * sizeof(float);
+#ifdef DVS_EMU
+    if (mu) memcpy(mu, ws + W.mu, nb);
+    if (logvar) memcpy(logvar, ws + W.logvar, nb);
+#else
+    if (mu) (void)hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st);
+    if (logvar) (void)hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st);
+#endif
+    return 0;
+}
+
+extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* params, void* workspace, float* mu,
+                          float* logvar, void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!records || !params || !workspace || !mu || !logvar) return fail(10, "dvs_encode: null pointer");
+    const DvsDims d = make_dims(s);
+    const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
+    const DvsWorkspace W = dvs_make_workspace(d.B, L.total, dvs_num_slabs());
+    float* ws = (float*)workspace;
+    dvs_stream_t st = (dvs_stream_t)stream;
+    encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, grid_for(d.B), st);
+    LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
+    la.dims.training = 0;
+    dvs_launch_latent_fwd(la, st);
+    const size_t nb = (size_t)d.B * 32 * sizeof(float);
+#ifdef DVS_EMU
+    memcpy(mu, ws + W.mu, nb);
+    memcpy(logvar, ws + W.logvar, nb);
+#else
+    (void)hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st);
+#endif
+    return 0;
+}
+
+extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
+    if (int e = check_shape(s)) return e;
+    const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
+    const DvsWorkspace W = dvs_make_workspace(s->batch, P, dvs_num_slabs());
+    const float* ws = (const float*)workspace;
+    const float* src = nullptr;
+    if (slot >= 0 && slot < DVS_NSLOTS) src = ws + W.act[slot];
+    else if (slot == 100) src = ws + W.enc_out;
+    else if (slot == 101) src = ws + W.mem;
+    else if (slot == 102) src = ws + W.gA;
+    else if (slot == 103) src = ws + W.gB;
+    else if (slot == 104) src = ws + W.gmem;
+    else if (slot == 105) src = ws + W.genc;
+    else return fail(11, "dvs_debug_activation: bad slot");
+    dvs_launch_unfrag(src, out, s->batch, (dvs_stream_t)stream);
+    return 0;
+}
+
+#include "dvs_api_backward.inc"

@@ -1,0 +1,297 @@
+// Device-side building blocks shared by every kernel of the PACE-VAE train step (gfx950 / CDNA4).
+//
+// Execution model: ONE WAVE (64 lanes) OWNS ONE DAG at a time and keeps the DAG's whole 16-token x 64-feature
+// activation tile in registers.  Lane l = 16*g + r (r = l & 15, g = l >> 4).  Two register layouts of a
+// [16 tokens x 64 features] tile, 16 VGPRs each (4 x float4):
+//
+//   T-layout  x[t][kk] = X[token r][feature 16t + 4g + kk]        (token on the lane's r, features on t,g,kk)
+//   N-layout  x[t][kk] = X[token 4g + kk][feature 16t + r]        (token on g,kk, features on t,r)
+//
+// They are exactly the operand/result maps of v_mfma_f32_16x16x4_f32 (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[i=4*(l>>4)+reg][j=l&15]), so every product of the network chains register-to-register:
+//   Y^T(T) = W   * X^T(T)   : mfma(a = W-row-fragment, b = x regs)       (linear layer, stays in T-layout)
+//   Y  (N) = X   * W^T      : mfma(a = x regs,         b = W-row-fragment) (same registers, operands swapped)
+//   dX^T(T)= W^T * dY^T(T)  : mfma(a = W-column-fragment, b = dy regs)
+//   dW    += dY(N)^T x X(N) : mfma(a = dyN regs, b = xN regs), 16 accumulators of 4 regs, D = dW[16ot+4g+reg][16it+r]
+// The contraction index of step (t,kk) is feature 16t+4g+kk (a k-permutation of the dot product; exact f32 fma
+// chain per MFMA, guide §3 'FP32-input MFMA').  Weights live in LDS as row-major [rows][DVS_LD] images
+// (DVS_LD = 68 floats: 16-byte aligned rows, b128 row-fragment reads at most 2-way conflicted, b32 column
+// reads conflict-free).  T<->N transposes go through a private per-wave LDS scratch tile.
+//
+// HBM layout of an activation tile ("frag order"): float4 index (dag*4 + t)*64 + lane holds x[t] of the
+// T-layout, so a wave's load/store of one t is one fully coalesced 1 KiB instruction.
+#pragma once
+
+#ifndef DVS_EMU
+#include <hip/hip_runtime.h>
+typedef float dvs_f32x4 __attribute__((ext_vector_type(4)));
+#define DVS_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#else
+#define DVS_DYN_LDS(name) char* name = emu::g_block->dyn_smem
+#endif
+
+#include <stdint.h>
+
+typedef dvs_f32x4 f4;
+
+constexpr int DVS_D = 64;        // d_model = ff_hidden_size (pace.py:1185)
+constexpr int DVS_LD = 68;       // LDS row stride in floats
+constexpr int DVS_TOK = 16;      // token slots per DAG tile (N = n + 3 <= 16)
+constexpr int DVS_TILE = DVS_TOK * DVS_D;   // floats per activation tile (frag order)
+constexpr int DVS_SCR = DVS_TOK * DVS_LD;   // floats of one per-wave scratch tile
+
+struct DvsRecord {               // compact per-DAG record written by dvs_pack_features (96 bytes)
+    uint8_t label[16];           // class index of token i (vertex_label_features argmax)
+    uint8_t pos[16];             // position index of token i (vertex_position_features argmax)
+    uint16_t parents[16];        // bit j: adjacency[j][i] == 1  (edge j -> i)
+    uint16_t allowed[16];        // bit j: token i may attend token j (target_masks[., i, j] == False)
+};
+
+struct Lane {
+    int lane, r, g, wave, nwaves;
+};
+
+__device__ __forceinline__ Lane dvs_lane() {
+    Lane L;
+    L.lane = threadIdx.x & 63;
+    L.r = L.lane & 15;
+    L.g = L.lane >> 4;
+    L.wave = threadIdx.x >> 6;
+    L.nwaves = blockDim.x >> 6;
+    return L;
+}
+
+__device__ __forceinline__ f4 dvs_mfma(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Orders this wave's earlier LDS writes before its later LDS reads by other lanes (a wave's DS operations are
+// executed in issue order; the wait makes that explicit).  In the host emulator lanes are fibers, so this is a
+// real wave-wide rendezvous.
+__device__ __forceinline__ void dvs_wave_sync() {
+#ifdef DVS_EMU
+    (void)emu::exchange(0, 0);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+__device__ __forceinline__ f4 f4_zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f4 f4_splat(float v) { return f4{v, v, v, v}; }
+
+// ---- weight images in LDS -----------------------------------------------------------------------------
+// copy a row-major [rows][cols] global matrix (leading dimension ldg) into an LDS image with stride ldl
+__device__ __forceinline__ void dvs_stage_matrix(float* dst, int ldl, const float* __restrict__ src, int ldg, int rows,
+                                                 int cols) {
+    const int c4 = cols >> 2;
+    for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
+        const int row = i / c4, c = (i - row * c4) << 2;
+        const float* s = src + (size_t)row * ldg + c;
+        *(f4*)(dst + row * ldl + c) = f4{s[0], s[1], s[2], s[3]};
+    }
+}
+__device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// row fragment: element kk = W[row0 + r][16t + 4g + kk]
+__device__ __forceinline__ f4 dvs_wrow(const float* W, int ld, int row0, int t, const Lane& L) {
+    return *(const f4*)(W + (row0 + L.r) * ld + 16 * t + 4 * L.g);
+}
+// column fragment: element kk = W[16t + 4g + kk][col0 + r]
+__device__ __forceinline__ f4 dvs_wcol(const float* W, int ld, int col0, int t, const Lane& L) {
+    const float* p = W + (16 * t + 4 * L.g) * ld + col0 + L.r;
+    return f4{p[0], p[ld], p[2 * ld], p[3 * ld]};
+}
+// feature vector (bias, LayerNorm gamma/beta) in T-layout: element kk = v[16t + 4g + kk]
+__device__ __forceinline__ f4 dvs_vecT(const float* v, int t, const Lane& L) { return *(const f4*)(v + 16 * t + 4 * L.g); }
+
+// ---- register-chained products ----------------------------------------------------------------------------
+// y^T[OT] (T) += W[row0 + 16*OT rows][16*IT cols] * x^T[IT] (T)
+template <int OT, int IT>
+__device__ __forceinline__ void dvs_mat_T(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f4 acc = y[ot];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const f4 w = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(w[kk], x[t][kk], acc);
+        }
+        y[ot] = acc;
+    }
+}
+// y[OT] (N) += x (T regs used as A) * W^T : y[dt][reg] = Y[token 4g+reg][16dt + r]
+template <int OT, int IT>
+__device__ __forceinline__ void dvs_mat_N(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f4 acc = y[ot];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const f4 w = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(x[t][kk], w[kk], acc);
+        }
+        y[ot] = acc;
+    }
+}
+// dx^T[IT] (T) += W^T * dy^T[OT] (T), W = [16*OT rows (row0..)][16*IT cols]
+template <int IT, int OT>
+__device__ __forceinline__ void dvs_mat_Tt(f4 (&dx)[IT], const f4 (&dy)[OT], const float* W, int ld, int row0, const Lane& L) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        f4 acc = dx[it];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            const f4 w = dvs_wcol(W + row0 * ld, ld, 16 * it, ot, L);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(w[kk], dy[ot][kk], acc);
+        }
+        dx[it] = acc;
+    }
+}
+// dW[ot][it] += dY(N)[ot]^T (x) X(N)[it] over this DAG's 16 tokens; D = dW[16ot + 4g + reg][16it + r]
+template <int OT, int IT>
+__device__ __forceinline__ void dvs_outer_acc(f4 (&dw)[OT][IT], const f4 (&dyN)[OT], const f4 (&xN)[IT]) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            f4 acc = dw[ot][it];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(dyN[ot][kk], xN[it][kk], acc);
+            dw[ot][it] = acc;
+        }
+}
+
+// ---- T <-> N transposes through the wave's private scratch tile [16][DVS_LD] ---------------------------------
+template <int NT>
+__device__ __forceinline__ void dvs_t2n(f4 (&out)[NT], const f4 (&in)[NT], float* scr, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *(f4*)(scr + L.r * DVS_LD + 16 * t + 4 * L.g) = in[t];
+    dvs_wave_sync();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* p = scr + (4 * L.g) * DVS_LD + 16 * t + L.r;
+        out[t] = f4{p[0], p[DVS_LD], p[2 * DVS_LD], p[3 * DVS_LD]};
+    }
+    dvs_wave_sync();
+}
+template <int NT>
+__device__ __forceinline__ void dvs_n2t(f4 (&out)[NT], const f4 (&in)[NT], float* scr, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* p = scr + (4 * L.g) * DVS_LD + 16 * t + L.r;
+        p[0] = in[t][0];
+        p[DVS_LD] = in[t][1];
+        p[2 * DVS_LD] = in[t][2];
+        p[3 * DVS_LD] = in[t][3];
+    }
+    dvs_wave_sync();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = *(const f4*)(scr + L.r * DVS_LD + 16 * t + 4 * L.g);
+    dvs_wave_sync();
+}
+
+// ---- frag-order HBM tiles -----------------------------------------------------------------------------------
+__device__ __forceinline__ void dvs_load_tile(f4 (&x)[4], const float* __restrict__ base, size_t dag, const Lane& L) {
+    const f4* p = (const f4*)(base + dag * DVS_TILE) + L.lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = p[t * 64];
+}
+__device__ __forceinline__ void dvs_store_tile(float* __restrict__ base, size_t dag, const f4 (&x)[4], const Lane& L) {
+    f4* p = (f4*)(base + dag * DVS_TILE) + L.lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t * 64] = x[t];
+}
+
+// ---- reductions over the 64 features of a token (T-layout: 16 in-lane values x 4 lane groups g) --------------
+__device__ __forceinline__ float dvs_sum_g(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float dvs_max_g(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float dvs_sum_r(float v) {   // over the 16 lanes r of one g group
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float dvs_sum_wave(float v) { return dvs_sum_g(dvs_sum_r(v)); }
+__device__ __forceinline__ float dvs_tile_sum(const f4 (&x)[4]) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+    return dvs_sum_g(s);
+}
+
+// LayerNorm statistics of token r over its 64 features (biased variance, eps 1e-5: torch.nn.LayerNorm)
+__device__ __forceinline__ void dvs_ln_stats(const f4 (&x)[4], float& mean, float& rstd) {
+    mean = dvs_tile_sum(x) * (1.f / 64.f);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float d = x[t][kk] - mean;
+            s += d * d;
+        }
+    rstd = 1.0f / sqrtf(dvs_sum_g(s) * (1.f / 64.f) + 1e-5f);
+}
+
+// ---- counter-based dropout / noise ------------------------------------------------------------------------------
+// Stateless: mask bits are a pure function of (seed, site, global DAG index, element), so the backward pass
+// regenerates them instead of storing 34 masks, and a batch sharded over ranks draws the same bits as the same
+// batch on one GPU.  oracle/rng.py restates these functions in numpy for the dropout-on parity tests.
+__device__ __forceinline__ uint32_t dvs_fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t dvs_site_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t site, uint32_t dag) {
+    uint32_t k = dvs_fmix32(seed_lo ^ ((site + 1u) * 0x632BE5ABu));
+    k = dvs_fmix32(k ^ seed_hi ^ (dag * 0x9E3779B1u));
+    return k;
+}
+// two Bernoulli(keep) draws for the element pair `pair` of one (site, dag): keep iff 16-bit half >= thr16
+__device__ __forceinline__ uint32_t dvs_draw(uint32_t key, uint32_t pair) { return dvs_fmix32(key ^ (pair * 0x9E3779B1u)); }
+
+struct DvsDrop {
+    uint32_t thr16;      // round(p * 65536); drop iff half < thr16
+    float scale;         // 1 / (1 - thr16/65536)
+    int on;              // training && p > 0
+};
+// element index of (token, feature) within a [16][64] site: tok*64 + f; a lane's f4 covers features 16t+4g..+3
+// -> pair indices (tok*64 + 16t + 4g)/2 and +1.
+__device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[4], uint32_t key, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t p0 = (uint32_t)(L.r * 64 + 16 * t + 4 * L.g) >> 1;
+        const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+        x[t][0] = ((h0 & 0xFFFFu) >= D.thr16) ? x[t][0] * D.scale : 0.f;
+        x[t][1] = ((h0 >> 16) >= D.thr16) ? x[t][1] * D.scale : 0.f;
+        x[t][2] = ((h1 & 0xFFFFu) >= D.thr16) ? x[t][2] * D.scale : 0.f;
+        x[t][3] = ((h1 >> 16) >= D.thr16) ? x[t][3] * D.scale : 0.f;
+    }
+}
+// single element (used for attention probabilities): element index e
+__device__ __forceinline__ float dvs_dropout_elem(float v, uint32_t key, uint32_t e, const DvsDrop& D) {
+    const uint32_t h = dvs_draw(key, e >> 1);
+    const uint32_t half = (e & 1u) ? (h >> 16) : (h & 0xFFFFu);
+    return (half >= D.thr16) ? v * D.scale : 0.f;
+}

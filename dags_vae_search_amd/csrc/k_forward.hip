@@ -1,0 +1,409 @@
+// Forward kernels of the PACE-VAE step: feature packing, embeddings, attention sublayer, FFN sublayer.
+// One wave owns one DAG (see dvs_device.h); workgroups are persistent and keep the sublayer's weights in LDS.
+#include "dvs_kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// dvs_pack_features: reference-layout dense features -> 96-byte records (replaces pace.py:1981-1985's
+// .to(device) hand-over; the features themselves come from prepare_features, pace.py:1345-1478).
+// One thread per (DAG, token slot).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dag = gid >> 4, i = gid & 15;
+    if (dag >= a.B) return;
+    const int N = a.N, C = a.C;
+    int bad = 0;
+    int label = 0, pos = 0;
+    unsigned parents = 0, allowed = 1u << i;
+    if (i < N) {
+        const float* lr = a.lab1h + ((size_t)dag * N + i) * C;
+        int ones = 0;
+        for (int c = 0; c < C; ++c) {
+            const float v = lr[c];
+            if (v == 1.0f) { label = c; ++ones; } else if (v != 0.0f) bad |= 1;
+        }
+        if (ones != 1) bad |= 1;
+        const float* pr = a.pos1h + ((size_t)dag * N + i) * N;
+        ones = 0;
+        for (int c = 0; c < N; ++c) {
+            const float v = pr[c];
+            if (v == 1.0f) { pos = c; ++ones; } else if (v != 0.0f) bad |= 1;
+        }
+        if (ones != 1) bad |= 1;
+        const float* ad = a.adj + (size_t)dag * N * N;
+        for (int j = 0; j < N; ++j)
+            if (ad[j * N + i] != 0.0f) parents |= 1u << j;
+        allowed = 0;
+        const uint8_t* m0 = a.tmask + ((size_t)dag * 8 * N + i) * N;
+        for (int j = 0; j < N; ++j)
+            if (!m0[j]) allowed |= 1u << j;
+        for (int h = 1; h < 8; ++h) {
+            const uint8_t* mh = a.tmask + (((size_t)dag * 8 + h) * N + i) * N;
+            for (int j = 0; j < N; ++j)
+                if ((mh[j] != 0) != (m0[j] != 0)) bad |= 2;
+        }
+        if (!((allowed >> i) & 1u)) bad |= 4;
+    }
+    DvsRecord* r = a.rec + dag;
+    r->label[i] = (uint8_t)label;
+    r->pos[i] = (uint8_t)pos;
+    r->parents[i] = (uint16_t)parents;
+    r->allowed[i] = (uint16_t)allowed;
+    if (bad) atomicOr(a.status, bad);
+}
+
+void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
+    const int threads = a.B * 16;
+    hipLaunchKernelGGL(k_pack, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding (GnnPositionalEncoding.forward pace.py:201-221 + vertex_label_embed 1181-1184 + cat 1624-1630).
+// One-hot inputs make both first layers row gathers:
+//   e1[i] = relu(W1[pos_i] + sum_{j parent of i} W1[N + pos_j]);  e2 = drop(drop(e1) @ W2)
+//   le[i] = relu(lab_w[:, label_i] + lab_b);                      x0 = cat(le, e2)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EMB_LDW2 = 36;
+struct EmbLds {
+    float *W1, *W2, *labw, *labb;
+};
+__device__ __forceinline__ EmbLds emb_lds(char* smem, int N, int C) {
+    EmbLds l;
+    l.W1 = (float*)smem;
+    l.W2 = l.W1 + 2 * DVS_MAXTOK * DVS_LD;
+    l.labw = l.W2 + 64 * EMB_LDW2;
+    l.labb = l.labw + 32 * 16;
+    return l;
+}
+static size_t emb_lds_floats() { return 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32; }
+
+// hidden of the positional encoder, T-layout [64 x tok], before dropout
+__device__ __forceinline__ void emb_hidden(f4 (&e1)[4], const EmbLds& l, const DvsRecord* rec, int N, const Lane& L) {
+    const bool valid = L.r < N;
+    const int pos = rec->pos[L.r];
+    const unsigned parents = rec->parents[L.r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) e1[t] = *(const f4*)(l.W1 + pos * DVS_LD + 16 * t + 4 * L.g);
+    for (int j = 0; j < N; ++j) {
+        const int pj = rec->pos[j];
+        const float on = ((parents >> j) & 1u) ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f4 w = *(const f4*)(l.W1 + (N + pj) * DVS_LD + 16 * t + 4 * L.g);
+            e1[t] += w * on;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) e1[t][kk] = valid ? fmaxf(e1[t][kk], 0.f) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
+    DVS_DYN_LDS(smem);
+    const int N = a.dims.N, C = a.dims.C;
+    const EmbLds l = emb_lds(smem, N, C);
+    dvs_stage_matrix(l.W1, DVS_LD, a.W1, 64, 2 * N, 64);
+    dvs_stage_matrix(l.W2, EMB_LDW2, a.W2, 32, 64, 32);
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
+        const int f = i >> 4, c = i & 15;
+        l.labw[i] = c < C ? a.lab_w[f * C + c] : 0.f;
+    }
+    dvs_stage_vector(l.labb, a.lab_b, 32);
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+        const DvsRecord* rec = a.rec + dag;
+        const bool valid = L.r < N;
+        f4 e1[4];
+        emb_hidden(e1, l, rec, N, L);
+        const uint32_t gdag = a.dims.dag_offset + dag;
+        dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site, gdag), D, L);
+        f4 x[4];
+        // positional half: e2^T[32 x tok] = W2^T e1^T  (A = W2 column fragments)
+        f4 e2[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f4 w = dvs_wcol(l.W2, EMB_LDW2, 16 * ot, t, L);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) e2[ot] = dvs_mfma(w[kk], e1[t][kk], e2[ot]);
+            }
+        {
+            f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
+            dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L);
+            x[2] = tmp[0];
+            x[3] = tmp[1];
+        }
+        // label half
+        const int label = rec->label[L.r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int f = 16 * t + 4 * L.g + kk;
+                x[t][kk] = valid ? fmaxf(l.labw[f * 16 + label] + l.labb[f], 0.f) : 0.f;
+            }
+        if (!valid) { x[2] = f4_zero(); x[3] = f4_zero(); }
+        dvs_store_tile(a.out, dag, x, L);
+    }
+}
+
+void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
+    const size_t lds = emb_lds_floats() * 4;
+    DVS_SET_LDS(k_embed_fwd, lds);
+    hipLaunchKernelGGL(k_embed_fwd, dim3(grid), dim3(256), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention sublayer forward: x = LN_prev(pre_prev); y = MHA(x, kv, kv, mask) (nn.MultiheadAttention explicit
+// path, pace.py:52-56 / 144 / 148); pre = x + dropout(y); stats(pre).  Everything between the tile load and the
+// tile store stays in registers:  q^T,k^T (T) -> S^T = K Q^T per head (lane r = query i, regs = keys 4g..4g+3)
+// -> softmax over keys (in-lane + 2 shuffles) -> O^T = V^T P^T -> y^T = Wo O^T.
+// ---------------------------------------------------------------------------------------------------------
+struct AttnLds {
+    float *Win, *Wout, *inb, *outb, *lg, *lb;
+};
+__device__ __forceinline__ AttnLds attn_lds(char* smem) {
+    AttnLds l;
+    l.Win = (float*)smem;
+    l.Wout = l.Win + 192 * DVS_LD;
+    l.inb = l.Wout + 64 * DVS_LD;
+    l.outb = l.inb + 192;
+    l.lg = l.outb + 64;
+    l.lb = l.lg + 64;
+    return l;
+}
+static size_t attn_lds_floats() { return 256 * DVS_LD + 192 + 64 + 128; }
+
+__device__ __forceinline__ void attn_stage(const AttnLds& l, const float* in_w, const float* in_b, const float* out_w,
+                                           const float* out_b, const DvsLN& ln) {
+    dvs_stage_matrix(l.Win, DVS_LD, in_w, 64, 192, 64);
+    dvs_stage_matrix(l.Wout, DVS_LD, out_w, 64, 64, 64);
+    dvs_stage_vector(l.inb, in_b, 192);
+    dvs_stage_vector(l.outb, out_b, 64);
+    if (ln.stats) {
+        dvs_stage_vector(l.lg, ln.g, 64);
+        dvs_stage_vector(l.lb, ln.b, 64);
+    }
+}
+
+// q^T, k^T (T-layout, q pre-scaled by 1/sqrt(dh)) and v (N-layout) of one DAG
+__device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], const f4 (&x)[4], const f4 (&kv)[4],
+                                         const AttnLds& l, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        q[t] = dvs_vecT(l.inb, t, L);
+        k[t] = dvs_vecT(l.inb + 64, t, L);
+        v[t] = f4_splat(l.inb[128 + 16 * t + L.r]);
+    }
+    dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
+    dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
+    dvs_mat_N<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
+    const float scale = 0.35355339059327373f;   // 1/sqrt(8)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q[t] *= scale;
+}
+
+// One head, "transposed" orientation: returns p[reg] = softmax_j(S[i=r][j=4g+reg]) (before dropout);
+// m, den = row max / denominator of query i = r.
+__device__ __forceinline__ f4 attn_probs_T(const f4& qt, const f4& kt, int hs, unsigned allowed_r, float& m, float& den,
+                                           const Lane& L) {
+    f4 s = f4_zero();
+    const bool mine = (L.g >> 1) == hs;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) s = dvs_mfma(mine ? kt[kk] : 0.f, qt[kk], s);
+    float mx = -3.0e38f;
+    bool ok[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
+        mx = ok[reg] ? fmaxf(mx, s[reg]) : mx;
+    }
+    m = dvs_max_g(mx);
+    f4 e;
+    float sum = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        e[reg] = ok[reg] ? __expf(s[reg] - m) : 0.f;
+        sum += e[reg];
+    }
+    den = dvs_sum_g(sum);
+    const float inv = 1.0f / den;
+    return e * inv;
+}
+
+// dropout on the probabilities of head h in the transposed orientation: element ((h*16 + i)*16 + j)
+__device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return p;
+    const uint32_t p0 = (uint32_t)((h * 16 + L.r) * 8 + 2 * L.g);
+    const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+    p[0] = ((h0 & 0xFFFFu) >= D.thr16) ? p[0] * D.scale : 0.f;
+    p[1] = ((h0 >> 16) >= D.thr16) ? p[1] * D.scale : 0.f;
+    p[2] = ((h1 & 0xFFFFu) >= D.thr16) ? p[2] * D.scale : 0.f;
+    p[3] = ((h1 >> 16) >= D.thr16) ? p[3] * D.scale : 0.f;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+    DVS_DYN_LDS(smem);
+    const AttnLds l = attn_lds(smem);
+    attn_stage(l, a.in_w, a.in_b, a.out_w, a.out_b, a.ln);
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int N = a.dims.N;
+    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+        f4 x[4], kv[4], dummy[4];
+        float rstd;
+        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+        if (a.kv) {
+            dvs_load_tile(kv, a.kv, dag, L);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) kv[t] = x[t];
+        }
+        f4 q[4], k[4], v[4];
+        attn_qkv(q, k, v, x, kv, l, L);
+        const unsigned allowed_r = a.rec[dag].allowed[L.r];
+        const uint32_t gdag = a.dims.dag_offset + dag;
+        const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
+        f4 o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t] = f4_zero();
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                float m, den;
+                f4 p = attn_probs_T(q[t], k[t], hs, allowed_r, m, den, L);
+                p = attn_drop_T(p, kprob, 2 * t + hs, D, L);
+                const bool mine = (L.r >> 3) == hs;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) o[t] = dvs_mfma(mine ? v[t][kk] : 0.f, p[kk], o[t]);
+            }
+        }
+        f4 y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);
+        dvs_mat_T<4, 4>(y, o, l.Wout, DVS_LD, 0, L);
+        dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
+        const bool valid = L.r < N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
+        dvs_store_pre(a.out_pre, a.out_stats, dag, y, L);
+    }
+}
+
+void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
+    const size_t lds = attn_lds_floats() * 4;
+    DVS_SET_LDS(k_attn_fwd, lds);
+    hipLaunchKernelGGL(k_attn_fwd, dim3(grid), dim3(256), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FFN sublayer forward (pace.py:62-65 / 151-153): pre = x + drop(W2 drop(relu(W1 x + b1)) + b2)
+// ---------------------------------------------------------------------------------------------------------
+struct FfnLds {
+    float *W1, *W2, *b1, *b2, *lg, *lb, *ng, *nb;
+};
+__device__ __forceinline__ FfnLds ffn_lds(char* smem) {
+    FfnLds l;
+    l.W1 = (float*)smem;
+    l.W2 = l.W1 + 64 * DVS_LD;
+    l.b1 = l.W2 + 64 * DVS_LD;
+    l.b2 = l.b1 + 64;
+    l.lg = l.b2 + 64;
+    l.lb = l.lg + 64;
+    l.ng = l.lb + 64;
+    l.nb = l.ng + 64;
+    return l;
+}
+static size_t ffn_lds_floats() { return 128 * DVS_LD + 6 * 64; }
+
+__global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
+    DVS_DYN_LDS(smem);
+    const FfnLds l = ffn_lds(smem);
+    dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
+    dvs_stage_matrix(l.W2, DVS_LD, a.l2_w, 64, 64, 64);
+    dvs_stage_vector(l.b1, a.l1_b, 64);
+    dvs_stage_vector(l.b2, a.l2_b, 64);
+    if (a.ln.stats) {
+        dvs_stage_vector(l.lg, a.ln.g, 64);
+        dvs_stage_vector(l.lb, a.ln.b, 64);
+    }
+    if (a.out_norm) {
+        dvs_stage_vector(l.ng, a.ng, 64);
+        dvs_stage_vector(l.nb, a.nb, 64);
+    }
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int N = a.dims.N;
+    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+        f4 x[4], dummy[4];
+        float rstd;
+        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+        const uint32_t gdag = a.dims.dag_offset + dag;
+        f4 h[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[t] = dvs_vecT(l.b1, t, L);
+        dvs_mat_T<4, 4>(h, x, l.W1, DVS_LD, 0, L);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) h[t][kk] = fmaxf(h[t][kk], 0.f);
+        dvs_dropout_tile(h, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag), D, L);
+        f4 y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.b2, t, L);
+        dvs_mat_T<4, 4>(y, h, l.W2, DVS_LD, 0, L);
+        dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
+        const bool valid = L.r < N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
+        float mean, rs;
+        dvs_ln_stats(y, mean, rs);
+        dvs_store_tile(a.out_pre, dag, y, L);
+        if (L.g == 0) {
+            a.out_stats[(size_t)dag * 32 + L.r] = mean;
+            a.out_stats[(size_t)dag * 32 + 16 + L.r] = rs;
+        }
+        if (a.out_norm) {
+            f4 xn[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f4 g = dvs_vecT(l.ng, t, L), b = dvs_vecT(l.nb, t, L);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) xn[t][kk] = valid ? (y[t][kk] - mean) * rs * g[kk] + b[kk] : 0.f;
+            }
+            dvs_store_tile(a.out_norm, dag, xn, L);
+        }
+    }
+}
+
+void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
+    const size_t lds = ffn_lds_floats() * 4;
+    DVS_SET_LDS(k_ffn_fwd, lds);
+    hipLaunchKernelGGL(k_ffn_fwd, dim3(grid), dim3(256), lds, st, a);
+}
+
+// frag-order [B][1024] -> natural [B][16][64] (debug / tests)
+__global__ void k_unfrag(const float* frag, float* out, int B) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * 1024) return;
+    const size_t dag = i >> 10;
+    const int e = (int)(i & 1023);
+    const int t = e >> 8, lane = (e >> 2) & 63, kk = e & 3;
+    const int r = lane & 15, g = lane >> 4;
+    out[dag * 1024 + r * 64 + 16 * t + 4 * g + kk] = frag[i];
+}
+void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st) {
+    const size_t n = (size_t)B * 1024;
+    hipLaunchKernelGGL(k_unfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frag, out, B);
+}

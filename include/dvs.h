@@ -1,0 +1,100 @@
+/* dvs.h — C ABI of libdvs_hip.so: the MI355X-native PACE-VAE train-step hot path.
+ *
+ * The reference (rlog58/dags-vae-search) is 100 % Python and has no FFI of its own: its boundary for this
+ * path is the Python class surface of PaceVaeV3 (src/encoders/pace.py:1139-2046) and train_batch
+ * (experiments/03_synthetic_12/main.py:95-118).  This header is the C ABI that sits UNDER the drop-in
+ * Python mirror (dags_vae_search_amd/pace.py, train.py); each entry point cites the reference code it
+ * replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every pointer marked "device" is device
+ * memory owned by the caller; the library never allocates or frees device memory and never synchronises
+ * the host with the device.  All work is enqueued on the passed HIP stream (void* = hipStream_t).
+ * Return value: 0 = ok, non-zero = error code; dvs_last_error() gives the thread-local message.
+ * Entry points are re-entrant (no global mutable state).
+ *
+ * Fixed architecture of this build (BASELINE.json configs; experiments/01_bn_asia/main.py:33-43):
+ * vertices_embedding_size 32, num_heads 8, num_layers 3, ff_hidden_size 64, latent_layer_size 32,
+ * fc_hidden 32.  n_tokens = n + 3 <= 16, n_classes = card + 3 <= 16.
+ */
+#ifndef DVS_H
+#define DVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVS_VERSION 100
+#define DVS_NUM_PARAMS 108
+#define DVS_RECORD_BYTES 96
+
+typedef struct dvs_shape {
+    int32_t batch;        /* DAGs in this (rank-local) batch */
+    int32_t n_tokens;     /* N = max_num_vertices + 3 (pace.py:1159), <= 16 */
+    int32_t n_classes;    /* C = vertex_label_cardinality + 3 (pace.py:1160), <= 16 */
+    int32_t training;     /* 1 = model.train(): dropout + reparameterisation noise; 0 = eval */
+    float dropout;        /* p of every nn.Dropout / attention dropout (pace.py:1150) */
+    float beta;           /* KL weight (pace.py:1977) */
+    float eps_scale;      /* epsilon_scale of reparameterize (pace.py:1653), 0.01 */
+    uint32_t dag_offset;  /* global index of this batch's first DAG (data-parallel shard offset) */
+    uint64_t seed;        /* counter-based RNG seed; fold the step number in on the host */
+} dvs_shape;
+
+typedef struct dvs_param_entry {
+    char name[64];        /* reference state-dict key, e.g. "encoder.layers.0.self_attn.in_proj_weight" */
+    int64_t offset;       /* float offset inside the flat parameter / gradient buffer (16-byte aligned) */
+    int32_t rows, cols;   /* cols == 0 for 1-D tensors */
+} dvs_param_entry;
+
+int dvs_version(void);
+const char* dvs_last_error(void);
+int dvs_device_cus(void);   /* compute units of the current device (grid sizing; informational) */
+
+/* Flat parameter buffer: the 108 tensors of PaceVaeV3.state_dict() (pace.py:1176-1207) in registration
+ * order, each 16-byte aligned.  dvs_param_table fills up to `cap` entries and returns the count. */
+int64_t dvs_param_count(const dvs_shape* s);
+int dvs_param_table(const dvs_shape* s, dvs_param_entry* out, int cap);
+
+/* Scratch needed by forward+backward for s->batch DAGs (saved activations, gradient slabs). */
+size_t dvs_workspace_bytes(const dvs_shape* s);
+
+/* Replaces the `.to(device)` feature hand-over at pace.py:1981-1985 / 1616-1619: reads the reference-layout
+ * dense features — vertex_label_features [B,N,C] f32, vertex_position_features [B,N,N] f32,
+ * adjacency_matrices [B,N,N] f32, target_masks [8B,N,N] bool (1 byte each) — and writes one 96-byte
+ * compact record per DAG.  status (device int32[1], zeroed by the caller) gets bit 0 set if a label/position
+ * row is not one-hot, bit 1 if the 8 per-head masks of a DAG differ, bit 2 if a mask row forbids self. */
+int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
+                      const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
+                      void* stream);
+
+/* PaceVaeV3.loss_direct forward (pace.py:1974-2035).  eps: optional device [B,32] noise already multiplied
+ * by eps_scale (NULL = counter-based normal draws when training).  losses (device f32[4]):
+ * {total, recon = -log-likelihood, kld, non-finite flag}.  mu/logvar: optional device [B,32] outputs. */
+int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
+                     const float* eps, float* losses, float* mu, float* logvar, void* stream);
+
+/* Backward of the same step (autograd of pace.py:1974-2035; experiments/03_synthetic_12/main.py:114).
+ * gcoef (device f32[2]): d(objective)/d(recon), d(objective)/d(kld).  grads: flat buffer, overwritten. */
+int dvs_loss_backward(const dvs_shape* s, const void* records, const float* params, void* workspace,
+                      const float* gcoef, float* grads, void* stream);
+
+/* PaceVaeV3.encode_direct (pace.py:1613-1641): mu, logvar device [B,32]. */
+int dvs_encode(const dvs_shape* s, const void* records, const float* params, void* workspace, float* mu,
+               float* logvar, void* stream);
+
+/* clip_grad_norm_(params, max_norm) + Adam.step (experiments/03_synthetic_12/main.py:115-116, lr 1e-4,
+ * betas (0.9, 0.999), eps 1e-8, no weight decay) over flat buffers of n floats.  max_norm <= 0 disables
+ * clipping.  scratch: device f32[2] ({sum of squares, clip coefficient}); `step` is the 1-based Adam step. */
+int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
+                  void* stream);
+
+/* Debug/test access: copy saved activation `slot` (natural [B,16,64] layout) out of the workspace. */
+int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,3 +1,182 @@
-// Backward kernel argument blocks + launchers (see k_backward*.hip).
+// Backward kernel argument blocks, launchers and the gradient-slab reduction helpers.
+//
+// Parameter gradients: every backward kernel runs on exactly `nslab` persistent workgroups.  A wave accumulates its
+// DAGs' weight-gradient contributions in registers (MFMA accumulators, dvs_outer_acc), the workgroup's waves are
+// summed in a fixed order through LDS, and the workgroup writes ONE partial ("slab") per parameter it owns to
+// slab[blockIdx][param offset].  k_reduce_slabs then sums the slabs in a fixed order into the flat gradient buffer:
+// no float atomics on HBM, bitwise reproducible gradients.
 #pragma once
 #include "dvs_kernels.h"
+
+struct FfnBwdArgs {
+    DvsDims dims;
+    const float* xin;            // pre-sum feeding this sublayer (or embedding output)
+    DvsLN ln;                    // LayerNorm of the producing sublayer (stats null = none)
+    const float *l1_w, *l1_b, *l2_w, *l2_b;
+    const float* gpre;           // d(pre of this sublayer)  — or d(LayerNorm(pre)) when `own` is set
+    // optional: the incoming gradient is w.r.t. LN_own(pre_own); pull it back through that LayerNorm first
+    const float* own_pre;
+    DvsLN own;
+    float* gout;                 // d(pre of the producing sublayer) (or d embedding output)
+    int site_hidden, site_post;
+    float* slab;
+    int64_t P;
+    int64_t o_l1_w, o_l1_b, o_l2_w, o_l2_b, o_ln_g, o_ln_b, o_own_g, o_own_b;   // -1 = absent
+};
+
+struct ProjBwdArgs {             // backward of 1..3 stacked 64->64 projections sharing one input X
+    DvsDims dims;
+    const float* xin;
+    DvsLN ln;                    // stats null: X is used as is (embedding output or decoder memory)
+    const float* w;              // first row of the stacked weight block [64*NPROJ][64]
+    const float* gy[3];          // d(projection outputs), T-layout frag tiles
+    const float* gres;           // optional residual gradient added to dX before the LayerNorm backward
+    float* gout;                 // result: d(pre of producer) / d(X)
+    int accumulate_out;          // 1: gout += (decoder memory gradient over layers)
+    float* slab;
+    int64_t P;
+    int64_t o_w, o_b, o_ln_g, o_ln_b;
+};
+
+struct AttnBwdArgs {
+    DvsDims dims;
+    const DvsRecord* rec;
+    const float* xin;
+    DvsLN ln;
+    const float* kv;             // null = self-attention
+    const float *in_w, *in_b, *out_w, *out_b;
+    const float* gpre;           // d(pre of this sublayer)
+    float *gq, *gk, *gv;         // outputs: d(q), d(k), d(v) projections (T-layout frag tiles)
+    int site_prob, site_post;
+    float* slab;
+    int64_t P;
+    int64_t o_out_w, o_out_b;
+};
+
+struct LatentBwdArgs {
+    DvsDims dims;
+    const float* gmem;           // d memory [B][1024]
+    const float *mu, *logvar, *epsv;
+    const float *fc1_w, *fc2_w, *fc3_w;
+    const float* gcoef;
+    float* gz;                   // [B][64] = d mu | d logvar
+    float* genc;                 // [B][1024] d enc_out
+};
+
+struct FcDwArgs {
+    DvsDims dims;
+    const float* gz;             // [B][64]
+    const float* xenc;           // [B][1024]
+    const float* gmem;           // [B][1024]
+    const float* z;              // [B][32]
+    float* slab;
+    int64_t P;
+    int nslab;
+    int64_t o_fc1_w, o_fc1_b, o_fc2_w, o_fc2_b, o_fc3_w, o_fc3_b;
+};
+
+struct ReduceArgs {
+    const float* slab;
+    float* grads;
+    int64_t P;
+    int nslab;
+};
+
+void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st);
+void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
+void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st);
+void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st);
+void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st);
+void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
+                          float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st);
+size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave);
+
+// ---- slab reduction helpers ---------------------------------------------------------------------------------------
+// Ordered sum over the workgroup's waves of register weight-gradient tiles dw[ot][it][reg] = dW[16ot+4g+reg][16it+r],
+// written as a dense [16*OT][16*IT] matrix to dst (global slab).  buf: LDS scratch of 256*OT*IT floats.
+// Must be called by ALL threads of the workgroup (contains barriers).
+template <int OT, int IT>
+__device__ __forceinline__ void dvs_reduce_dw(float* buf, const f4 (&dw)[OT][IT], float* dst, const Lane& L,
+                                              int rows = 16 * OT, int ld_dst = 16 * IT) {
+    constexpr int COLS = 16 * IT;
+    for (int w = 0; w < L.nwaves; ++w) {
+        if (L.wave == w) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ot + 4 * L.g + reg) * COLS + 16 * it + L.r;
+                        buf[idx] = (w == 0 ? 0.f : buf[idx]) + dw[ot][it][reg];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
+        const int row = i / COLS, col = i - row * COLS;
+        dst[(size_t)row * ld_dst + col] = buf[i];
+    }
+    __syncthreads();
+}
+// Same for a per-feature vector kept as T-layout per-lane partial sums v[t][kk] (feature 16t+4g+kk, summed over
+// the tokens r this lane handled): reduce over r with shuffles, then over waves through LDS.  n = 16*NT floats.
+template <int NT>
+__device__ __forceinline__ void dvs_reduce_vec(float* buf, const f4 (&v)[NT], float* dst, const Lane& L, int n = 16 * NT) {
+    f4 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s[t][kk] = dvs_sum_r(v[t][kk]);
+    for (int w = 0; w < L.nwaves; ++w) {
+        if (L.wave == w && L.r == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int idx = 16 * t + 4 * L.g + kk;
+                    buf[idx] = (w == 0 ? 0.f : buf[idx]) + s[t][kk];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = buf[i];
+    __syncthreads();
+}
+
+// LayerNorm backward for token r (T-layout): given dx (gradient w.r.t. the LayerNorm output), xhat, rstd and gamma,
+// returns d(pre) in place and accumulates d gamma / d beta partials.
+__device__ __forceinline__ void dvs_ln_bwd(f4 (&dx)[4], const f4 (&xhat)[4], float rstd, const float* lg, f4 (&dgam)[4],
+                                           f4 (&dbet)[4], const Lane& L) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f4 g = dvs_vecT(lg, t, L);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            dgam[t][kk] += dx[t][kk] * xhat[t][kk];
+            dbet[t][kk] += dx[t][kk];
+            const float dxh = dx[t][kk] * g[kk];
+            dx[t][kk] = dxh;
+            s1 += dxh;
+            s2 += dxh * xhat[t][kk];
+        }
+    }
+    s1 = dvs_sum_g(s1) * (1.f / 64.f);
+    s2 = dvs_sum_g(s2) * (1.f / 64.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dx[t][kk] = rstd * (dx[t][kk] - s1 - xhat[t][kk] * s2);
+}
+
+__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L) {
+    dvs_load_tile(g, base, dag, L);
+    if (L.r >= N) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = f4_zero();
+    }
+}

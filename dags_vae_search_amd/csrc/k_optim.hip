@@ -1,0 +1,55 @@
+// clip_grad_norm_ + Adam over the flat parameter buffer (experiments/03_synthetic_12/main.py:115-116).
+#include "dvs_backward.h"
+
+// Deterministic global L2 norm: one workgroup, fixed summation order.  scratch[0] = sum of squares,
+// scratch[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_).
+__global__ __launch_bounds__(1024) void k_sqnorm(const float* g, int64_t n, float max_norm, float* scratch) {
+    __shared__ float part[1024];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const f4 v = *(const f4*)(g + 4 * i);
+        s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) s += g[i] * g[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ss = part[0];
+        scratch[0] = ss;
+        float coef = 1.0f;
+        if (max_norm > 0.f) {
+            coef = max_norm / (sqrtf(ss) + 1e-6f);
+            coef = coef < 1.0f ? coef : 1.0f;
+        }
+        scratch[1] = coef;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
+                                              float eps, float bc1, float bc2_sqrt, const float* scratch) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float coef = scratch[1];
+    const float gi = g[i] * coef;
+    g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
+                          float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st) {
+    hipLaunchKernelGGL(k_sqnorm, dim3(1), dim3(1024), 0, st, (const float*)grads, n, max_norm, scratch);
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
+                       bc1, sqrtf(bc2), (const float*)scratch);
+}

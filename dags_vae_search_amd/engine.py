@@ -1,0 +1,139 @@
+"""Thin host-side driver of the C ABI (include/dvs.h) over torch device memory and streams.
+
+PyTorch is plumbing here: it owns the device buffers and the stream; all arithmetic happens inside
+libdvs_hip.so.  Every method requires CUDA (ROCm) tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as dl
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"dags_vae_search_amd: {what} must live on the GPU (got device {t.device}); "
+                           f"this package has no CPU path")
+
+
+class PaceEngine:
+    """Workspace + record buffers for one (n_tokens, n_classes) model; sized lazily per batch size."""
+
+    def __init__(self, n_tokens: int, n_classes: int):
+        self.lib = dl.load()
+        self.n_tokens = int(n_tokens)
+        self.n_classes = int(n_classes)
+        shape = dl.make_shape(1, n_tokens, n_classes)
+        if self.lib.dvs_param_count(ctypes.byref(shape)) < 0:
+            dl.check(self.lib, 1, "dvs_param_count")
+        self.table, self.param_floats = dl.param_table(self.lib, shape)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+        self._records: Optional[torch.Tensor] = None
+        self._status: Optional[torch.Tensor] = None
+
+    # ---- buffers -------------------------------------------------------------------------------------
+    def shape(self, batch, training=False, dropout=0.15, beta=0.005, eps_scale=0.01, dag_offset=0, seed=0):
+        return dl.make_shape(batch, self.n_tokens, self.n_classes, training, dropout, beta, eps_scale, dag_offset, seed)
+
+    def workspace(self, batch: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws_batch != batch or self._ws.device != device:
+            shape = self.shape(batch)
+            nbytes = self.lib.dvs_workspace_bytes(ctypes.byref(shape))
+            if nbytes == 0:
+                dl.check(self.lib, 1, "dvs_workspace_bytes")
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            self._ws_batch = batch
+            self._records = torch.empty(batch * dl.RECORD_BYTES, dtype=torch.uint8, device=device)
+            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._ws
+
+    # ---- entry points ----------------------------------------------------------------------------------
+    def pack(self, features: Dict, check: bool = True) -> torch.Tensor:
+        """dvs_pack_features: reference-layout dense feature tensors (already on the GPU) -> records."""
+        lab = features["vertex_label_features"]
+        pos = features["vertex_position_features"]
+        adj = features["adjacency_matrices"]
+        tm = features["target_masks"]
+        for name, t in (("vertex_label_features", lab), ("vertex_position_features", pos),
+                        ("adjacency_matrices", adj), ("target_masks", tm)):
+            _require_cuda(t, name)
+        B, N, C = lab.shape
+        if N != self.n_tokens or C != self.n_classes:
+            raise AssertionError(f"Expected [B,{self.n_tokens},{self.n_classes}] label features, got {tuple(lab.shape)}")
+        if tuple(pos.shape) != (B, N, N) or tuple(adj.shape) != (B, N, N) or tuple(tm.shape) != (8 * B, N, N):
+            raise AssertionError("feature tensors have inconsistent shapes")
+        lab = lab.contiguous().float()
+        pos = pos.contiguous().float()
+        adj = adj.contiguous().float()
+        tm = tm.contiguous()
+        tm = tm.view(torch.uint8) if tm.dtype == torch.bool else tm.to(torch.uint8)
+        self.workspace(B, lab.device)
+        self._status.zero_()
+        shape = self.shape(B)
+        dl.check(self.lib, self.lib.dvs_pack_features(ctypes.byref(shape), _ptr(lab), _ptr(pos), _ptr(adj), _ptr(tm),
+                                                      _ptr(self._records), _ptr(self._status), _stream()),
+                 "dvs_pack_features")
+        if check:
+            st = int(self._status.item())
+            if st:
+                raise ValueError(f"features violate the prepare_features invariants (status bits {st:#x}: "
+                                 f"1 = label/position row not one-hot, 2 = per-head masks differ, 4 = self masked)")
+        return self._records
+
+    def loss_forward(self, shape, params: torch.Tensor, eps: Optional[torch.Tensor], losses: torch.Tensor,
+                     mu: Optional[torch.Tensor] = None, logvar: Optional[torch.Tensor] = None):
+        _require_cuda(params, "parameters")
+        ws = self.workspace(shape.batch, params.device)
+        dl.check(self.lib, self.lib.dvs_loss_forward(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
+                                                     _ptr(eps), _ptr(losses), _ptr(mu), _ptr(logvar), _stream()),
+                 "dvs_loss_forward")
+
+    def loss_backward(self, shape, params: torch.Tensor, gcoef: torch.Tensor, grads: torch.Tensor):
+        ws = self.workspace(shape.batch, params.device)
+        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
+                                                      _ptr(gcoef), _ptr(grads), _stream()), "dvs_loss_backward")
+
+    def encode(self, shape, params: torch.Tensor, mu: torch.Tensor, logvar: torch.Tensor):
+        ws = self.workspace(shape.batch, params.device)
+        dl.check(self.lib, self.lib.dvs_encode(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
+                                               _ptr(mu), _ptr(logvar), _stream()), "dvs_encode")
+
+    def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch):
+        dl.check(self.lib, self.lib.dvs_clip_adam(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg),
+                                                  _ptr(exp_avg_sq), lr, beta1, beta2, eps, int(step), float(max_norm),
+                                                  _ptr(scratch), _stream()), "dvs_clip_adam")
+
+    def activation(self, batch: int, slot: int) -> torch.Tensor:
+        out = torch.empty(batch, 16, 64, dtype=torch.float32, device=self._ws.device)
+        shape = self.shape(batch)
+        dl.check(self.lib, self.lib.dvs_debug_activation(ctypes.byref(shape), _ptr(self._ws), slot, _ptr(out), _stream()),
+                 "dvs_debug_activation")
+        return out
+
+    def flatten(self, params: Dict[str, torch.Tensor], device) -> torch.Tensor:
+        flat = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
+        for name, off, shp in self.table:
+            v = params[name].detach().to(device=device, dtype=torch.float32).reshape(-1)
+            flat[off:off + v.numel()] = v
+        return flat
+
+    def unflatten(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for name, off, shp in self.table:
+            n = 1
+            for s in shp:
+                n *= s
+            out[name] = flat[off:off + n].view(shp)
+        return out

@@ -129,24 +129,48 @@ def init_params(cfg: PaceConfig, seed: int = 42) -> Dict[str, torch.Tensor]:
     return p
 
 
-def _drop(x, p, training):
-    return F.dropout(x, p, training) if (training and p > 0.0) else x
+def _drop(x, p, training, mask=None):
+    """nn.Dropout.  `mask` (already scaled by 1/keep, same shape as x) replaces torch's own draw when given:
+    the parity tests inject the device's counter-based masks (oracle/rng.py)."""
+    if not (training and p > 0.0):
+        return x
+    if mask is not None:
+        return x * mask
+    return F.dropout(x, p, training)
 
 
-def _embed(P, cfg, lab1h, pos1h, adj, training):
+def _tile_mask(masks, site, x_bnf):
+    """mask for a [B, N, width] tensor at dropout site `site` (None when torch's RNG is used)."""
+    if masks is None:
+        return None
+    B, N, W = x_bnf.shape
+    return torch.from_numpy(masks.tile(site, B, N, W))
+
+
+# dropout sites (dags_vae_search_amd/csrc/dvs_api.hip site_enc/site_dec): 0,1 encoder-side embedding; 2,3 decoder-side
+# embedding; 4+4l+{0 attn weights, 1 post-attn, 2 ffn hidden, 3 post-ffn}; 16+6l+{0,1 self; 2,3 cross; 4,5 ffn}
+def site_enc(layer, k):
+    return 4 + 4 * layer + k
+
+
+def site_dec(layer, k):
+    return 16 + 6 * layer + k
+
+
+def _embed(P, cfg, lab1h, pos1h, adj, training, masks=None, site=0):
     """pace.py:201-221 + 1181-1184 + cat (1624-1630): -> [B, N, 64]."""
     pe = torch.cat((pos1h, torch.matmul(adj.transpose(1, 2), pos1h)), 2)
     pe = torch.relu(torch.matmul(pe, P["vertex_position_embed.W1"]))
     if cfg.dropout > 0.0001:
-        pe = _drop(pe, cfg.dropout, training)
+        pe = _drop(pe, cfg.dropout, training, _tile_mask(masks, site, pe))
     pe = torch.matmul(pe, P["vertex_position_embed.W2"])
     if cfg.dropout > 0.0001:
-        pe = _drop(pe, cfg.dropout, training)
+        pe = _drop(pe, cfg.dropout, training, _tile_mask(masks, site + 1, pe))
     le = torch.relu(F.linear(lab1h, P["vertex_label_embed.0.weight"], P["vertex_label_embed.0.bias"]))
     return torch.cat([le, pe], 2)
 
 
-def _mha(P, prefix, cfg, q_in, kv_in, mask_bool, training):
+def _mha(P, prefix, cfg, q_in, kv_in, mask_bool, training, masks=None, site=0):
     """nn.MultiheadAttention(64, 8, dropout) explicit path (need_weights=True default, pace.py:52-56):
     packed in-proj, q scaled by 1/sqrt(dh), additive -inf mask, softmax, dropout on weights, out-proj.
     q_in/kv_in: [L, B, d]; mask_bool: [B*H, L, S] (True = masked)."""
@@ -164,7 +188,7 @@ def _mha(P, prefix, cfg, q_in, kv_in, mask_bool, training):
     add_mask = torch.zeros(mask_bool.shape, dtype=q.dtype).masked_fill_(mask_bool, float("-inf"))
     w = torch.baddbmm(add_mask, q, k.transpose(1, 2))
     w = torch.softmax(w, dim=-1)
-    w = _drop(w, cfg.dropout, training)
+    w = _drop(w, cfg.dropout, training, None if masks is None else torch.from_numpy(masks.attn(site, B, L, H)))
     o = torch.bmm(w, v).transpose(0, 1).reshape(L, B, d)
     return F.linear(o, P[prefix + ".out_proj.weight"], P[prefix + ".out_proj.bias"])
 
@@ -173,41 +197,49 @@ def _ln(P, name, x):
     return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], 1e-5)
 
 
-def _ffn(P, prefix, cfg, x, training):
+def _seq_mask(masks, site, x_lbd):
+    """mask for a sequence-first [L, B, d] activation."""
+    if masks is None:
+        return None
+    L, B, d = x_lbd.shape
+    return torch.from_numpy(masks.tile(site, B, L, d)).transpose(0, 1)
+
+
+def _ffn(P, prefix, cfg, x, training, masks=None, site=0):
     h = torch.relu(F.linear(x, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
-    h = _drop(h, cfg.dropout, training)
+    h = _drop(h, cfg.dropout, training, _seq_mask(masks, site, h))
     return F.linear(h, P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"])
 
 
-def _encoder(P, cfg, x, mask, training):
+def _encoder(P, cfg, x, mask, training, masks=None):
     for l in range(cfg.layers):
         pre = f"encoder.layers.{l}"
-        a = _mha(P, pre + ".self_attn", cfg, x, x, mask, training)
-        x = _ln(P, pre + ".norm1", x + _drop(a, cfg.dropout, training))
-        f = _ffn(P, pre, cfg, x, training)
-        x = _ln(P, pre + ".norm2", x + _drop(f, cfg.dropout, training))
+        a = _mha(P, pre + ".self_attn", cfg, x, x, mask, training, masks, site_enc(l, 0))
+        x = _ln(P, pre + ".norm1", x + _drop(a, cfg.dropout, training, _seq_mask(masks, site_enc(l, 1), a)))
+        f = _ffn(P, pre, cfg, x, training, masks, site_enc(l, 2))
+        x = _ln(P, pre + ".norm2", x + _drop(f, cfg.dropout, training, _seq_mask(masks, site_enc(l, 3), f)))
         if torch.isnan(x).any():  # pace.py:97-98
             raise ValueError(f"NaN detected in the output of encoder layer {l}")
     return x
 
 
-def _decoder(P, cfg, t, memory, mask, training):
+def _decoder(P, cfg, t, memory, mask, training, masks=None):
     for l in range(cfg.layers):
         pre = f"decoder.layers.{l}"
-        a = _mha(P, pre + ".self_attn", cfg, t, t, mask, training)
-        t = _ln(P, pre + ".norm1", t + _drop(a, cfg.dropout, training))
-        a = _mha(P, pre + ".multihead_attn", cfg, t, memory, mask, training)   # tgt_mask, pace.py:148
-        t = _ln(P, pre + ".norm2", t + _drop(a, cfg.dropout, training))
-        f = _ffn(P, pre, cfg, t, training)
-        t = _ln(P, pre + ".norm3", t + _drop(f, cfg.dropout, training))
+        a = _mha(P, pre + ".self_attn", cfg, t, t, mask, training, masks, site_dec(l, 0))
+        t = _ln(P, pre + ".norm1", t + _drop(a, cfg.dropout, training, _seq_mask(masks, site_dec(l, 1), a)))
+        a = _mha(P, pre + ".multihead_attn", cfg, t, memory, mask, training, masks, site_dec(l, 2))   # tgt_mask, pace.py:148
+        t = _ln(P, pre + ".norm2", t + _drop(a, cfg.dropout, training, _seq_mask(masks, site_dec(l, 3), a)))
+        f = _ffn(P, pre, cfg, t, training, masks, site_dec(l, 4))
+        t = _ln(P, pre + ".norm3", t + _drop(f, cfg.dropout, training, _seq_mask(masks, site_dec(l, 5), f)))
     return t
 
 
-def encode_direct(P, cfg: PaceConfig, features: Dict, training: bool = False):
+def encode_direct(P, cfg: PaceConfig, features: Dict, training: bool = False, masks=None):
     """pace.py:1613-1641 -> (mu, logvar) [B, latent]."""
     x = _embed(P, cfg, features["vertex_label_features"], features["vertex_position_features"],
-               features["adjacency_matrices"], training)
-    mem = _encoder(P, cfg, x.transpose(0, 1), features["target_masks"], training)
+               features["adjacency_matrices"], training, masks, 0)
+    mem = _encoder(P, cfg, x.transpose(0, 1), features["target_masks"], training, masks)
     flat = mem.transpose(0, 1).reshape(-1, cfg.N * cfg.d_model)
     return (F.linear(flat, P["fc1.weight"], P["fc1.bias"]),
             F.linear(flat, P["fc2.weight"], P["fc2.bias"]))
@@ -242,10 +274,11 @@ def log_likelihood(P, cfg: PaceConfig, features: Dict, dec_out: torch.Tensor) ->
 
 
 def loss_direct(P, cfg: PaceConfig, features: Dict, beta: float = 0.005, training: bool = False,
-                eps: Optional[torch.Tensor] = None, return_aux: bool = False):
+                eps: Optional[torch.Tensor] = None, return_aux: bool = False, masks=None):
     """pace.py:1974-2035 -> (total, recon, kld).  ``eps`` (already scaled by epsilon_scale=0.01)
-    replaces the reference's ``randn_like(std) * 0.01`` draw when given (train mode only)."""
-    mu, logvar = encode_direct(P, cfg, features, training)
+    replaces the reference's ``randn_like(std) * 0.01`` draw when given (train mode only).  ``masks``
+    (oracle.rng.DeviceMasks) injects the device's dropout masks instead of torch's own draws."""
+    mu, logvar = encode_direct(P, cfg, features, training, masks)
     if training:
         std = torch.exp(0.5 * logvar)
         if eps is None:
@@ -255,8 +288,8 @@ def loss_direct(P, cfg: PaceConfig, features: Dict, beta: float = 0.005, trainin
         z = mu
     mem = F.linear(z, P["fc3.weight"], P["fc3.bias"]).reshape(-1, cfg.N, cfg.d_model).transpose(0, 1)
     x = _embed(P, cfg, features["vertex_label_features"], features["vertex_position_features"],
-               features["adjacency_matrices"], training)
-    dec = _decoder(P, cfg, x.transpose(0, 1), mem, features["target_masks"], training).transpose(0, 1)
+               features["adjacency_matrices"], training, masks, 2)
+    dec = _decoder(P, cfg, x.transpose(0, 1), mem, features["target_masks"], training, masks).transpose(0, 1)
     ll = log_likelihood(P, cfg, features, dec)
     kld = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
     total = -ll + beta * kld
@@ -276,9 +309,9 @@ class OracleTrainer:
         self.opt = torch.optim.Adam(list(self.P.values()), lr=lr)
         self.max_grad_norm = max_grad_norm
 
-    def step(self, features: Dict, training: bool = True, eps: Optional[torch.Tensor] = None):
+    def step(self, features: Dict, training: bool = True, eps: Optional[torch.Tensor] = None, masks=None):
         self.opt.zero_grad()
-        total, recon, kld = loss_direct(self.P, self.cfg, features, training=training, eps=eps)
+        total, recon, kld = loss_direct(self.P, self.cfg, features, training=training, eps=eps, masks=masks)
         value = float(total.item())
         total.backward()
         torch.nn.utils.clip_grad_norm_(list(self.P.values()), self.max_grad_norm)

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — DAGs/sec of the PACE-VAE train step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full train step on one batch of synthetic DAGs whose reference-layout dense features are already
+resident in HBM: dvs_pack_features -> forward -> backward -> (RCCL SUM all-reduce of the flat gradient when N > 1)
+-> fused clip_grad_norm_(1.0) + Adam(lr 1e-4), in train mode with dropout 0.15 — i.e. train_batch() of
+experiments/03_synthetic_12/main.py:95-118 including its loss.item() host read.  Workload: BASELINE configs[1]/metric
+shape: synthetic n=12, card=12, batch 4096 per GPU (weak scaling: global batch = 4096 * N, one gradient all-reduce).
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (per-kernel durations measured with
+HIP events on the launch stream inside libdvs_hip.so) and "cpu_baseline" (the oracle = CPU port of the reference step,
+timed on this box's host cores on a bounded sample; rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+N_VERT, CARD = 12, 12
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix/vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def algo_flops_per_dag(N: int, C: int):
+    """Algorithmic FLOPs per DAG of each kernel (multiply-add = 2), counted on the TRUE token count N (not the
+    16-token tile) and on the reference's formulation (the edge head in its factored U_i+V_j form).
+    proj = one N x 64 x 64 projection; core = QK^T + PV of all 8 heads."""
+    proj = 2.0 * N * 64 * 64
+    core = 2.0 * 2 * N * N * 64
+    pairs = (N - 1) * (N - 2) / 2
+    node = 2.0 * N * (64 * 32 + 32 * C)
+    edge = 2 * proj + pairs * 64 * 3
+    emb = 2.0 * N * 64 * 32 + N * 64 * 3
+    latent_f = 2.0 * N * 64 * 64 + 2.0 * 32 * N * 64
+    return {
+        "k_embed_fwd": emb, "k_attn_fwd": 4 * proj + core, "k_ffn_fwd": 2 * proj, "k_latent_fwd": latent_f,
+        "k_loss_fwd": node + edge,
+        # backward kernels: recompute (1x forward) + gradients (2x forward) of the ops they own
+        "k_loss_bwd": 3 * (node + edge), "k_ffn_bwd": 3 * 2 * proj,
+        "k_attn_bwd": (3 * proj + core) + 2 * (proj + core) + proj,     # recompute q,k,v,P ; dWo,dO + core bwd ; O
+        "k_proj_bwd<3>": 2 * 3 * proj, "k_proj_bwd<2>": 2 * 2 * proj, "k_proj_bwd<1>": 2 * proj,
+        "k_latent_bwd": 2.0 * 32 * N * 64 + 2.0 * N * 64 * 64, "k_fc_dw": latent_f, "k_embed_bwd": 2 * emb,
+    }
+
+
+def bytes_per_dag(N: int, C: int, P: int, B_local: int) -> float:
+    """SURVEY.md §8d algorithmic bytes per DAG: consumed reference-layout features + amortised parameter traffic."""
+    return N * C * 4 + 2 * N * N * 4 + 8 * N * N + 9.0 * P * 4 / B_local
+
+
+def make_batch(batch: int, seed: int, device):
+    from dags_vae_search_amd import prepare_features
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    graphs = synthetic_dags(N_VERT, CARD, batch, seed=seed)
+    feats = prepare_features(graphs, N_VERT + 3, CARD + 3)
+    dev_feats = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in feats.items()}
+    return graphs, feats, dev_feats
+
+
+def cpu_baseline(graphs, feats, steps: int = 3):
+    """Reference CPU path = oracle port of train_batch (train mode, dropout 0.15, Adam), all host cores."""
+    from oracle import pace_oracle as po
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = po.PaceConfig(n=N_VERT, card=CARD)
+    torch.manual_seed(42)
+    tr = po.OracleTrainer(cfg, po.init_params(cfg, seed=42))
+    f = {k: v for k, v in feats.items()}
+    tr.step(f)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(f)
+    dt = (time.perf_counter() - t0) / steps
+    B = len(graphs)
+    return {"value": B / dt, "unit": "DAGs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed train steps (+1 warm-up) of the oracle on the same n={N_VERT} card={CARD} "
+                      f"B={B} batch, torch CPU fp32, {cores} threads", "ms_per_step": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="DAGs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from dags_vae_search_amd import PaceVaeV3, optim as dopt
+    from dags_vae_search_amd import _lib as dl
+    from dags_vae_search_amd.train import train_batch
+
+    torch.manual_seed(42)          # experiments/03_synthetic_12/main.py:122-124: same initial weights on every rank
+    model = PaceVaeV3(max_num_vertices=N_VERT, vertex_label_cardinality=CARD, vertices_embedding_size=32, num_heads=8,
+                      num_layers=3, ff_hidden_size=64, latent_layer_size=32, fc_hidden=32, dropout=0.15).to(device)
+    model.seed(42)
+    model.dag_offset = rank * args.batch
+    opt = dopt.Adam(model.parameters(), lr=1e-4).attach(model)
+    graphs, feats, dev_feats = make_batch(args.batch, seed=42 + rank, device=device)
+    group = True if distributed else None
+
+    def step():
+        return train_batch(dev_feats, model, opt, max_grad_norm=1.0, group=group)
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_value, _, _ = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    global_batch = args.batch * world
+    value = global_batch * args.steps / dt
+
+    # ---- per-kernel durations (HIP events on the launch stream), separate untimed steps --------------------------------
+    lib = dl.load()
+    lib.dvs_profile_enable(1)
+    prof_steps = 3
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof = dl.profile_collect(lib)
+    lib.dvs_profile_enable(0)
+    sync()
+
+    if rank == 0:
+        N, C = N_VERT + 3, CARD + 3
+        P = sum(p.numel() for p in model.parameters())
+        flops = algo_flops_per_dag(N, C)
+        kern = {k: {"launches_per_step": c // prof_steps, "avg_us": 1e3 * ms / c, "ms_per_step": ms / prof_steps}
+                for k, (c, ms) in prof.items()}
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        ach = flops.get(dom, 0.0) * args.batch / (kern[dom]["avg_us"] * 1e-6) / 1e12
+        step_flops = 3 * 8.46e6 if (N_VERT, CARD) == (12, 12) else sum(flops.values())
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
+                    "algorithmic_flops_per_dag": flops.get(dom, 0.0),
+                    "whole_step": {"tflops": value / world * step_flops / 1e12,
+                                   "frac_f32_mfma_peak": value / world * step_flops / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "hbm_algorithmic_GBs": value / world * bytes_per_dag(N, C, P, args.batch) / 1e9,
+                                   "frac_hbm_peak": value / world * bytes_per_dag(N, C, P, args.batch) / 1e9 / PEAK_HBM_GBS,
+                                   "gpu_kernel_ms_per_step": sum(k["ms_per_step"] for k in kern.values())}}
+        out = {
+            "metric": "DAGs/sec VAE+predictor train step, n=12 batch 4096",
+            "value": value, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic_v12 DAGs (n=12, card=12, N=15 tokens), PACE-VAE train step: pack + fwd + bwd"
+                                   " + clip_grad_norm_(1.0) + Adam(1e-4), train mode dropout 0.15",
+                       "per_gpu_batch": args.batch, "global_batch": global_batch,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "last_loss_per_dag": loss_value / global_batch},
+            "roofline": roofline,
+            "kernels": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(graphs, feats)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""dags_vae_search_amd — MI355X-native DAG-VAE (PACE) train-step hot path of rlog58/dags-vae-search.
+
+Drop-in surface for that path: PaceVaeV3, train_batch, pace_collate_fn, collate_graph_batch, load_model_state,
+LabeledDag (row codec).  All arithmetic runs in libdvs_hip.so (hand-written HIP for gfx950); there is no CPU path.
+"""
+from .features import LabeledDag, LabeledGraph, collate_graph_batch, pace_collate_fn, prepare_features  # noqa: F401
+from .pace import PaceVaeV3  # noqa: F401
+from .train import load_model_state, train_batch, train_model  # noqa: F401
+from . import optim  # noqa: F401

@@ -52,6 +52,10 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_clip_adam.restype = c_int
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_int64, c_float, c_void_p, c_void_p]
+    lib.dvs_profile_enable.restype = None
+    lib.dvs_profile_enable.argtypes = [c_int]
+    lib.dvs_profile_collect.restype = c_int
+    lib.dvs_profile_collect.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int]
     lib.dvs_debug_activation.restype = c_int
     lib.dvs_debug_activation.argtypes = [P(DvsShape), c_void_p, c_int, c_void_p, c_void_p]
     return lib
@@ -59,7 +63,20 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
            "dvs_workspace_bytes", "dvs_pack_features", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
-           "dvs_clip_adam", "dvs_debug_activation"]
+           "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
+
+
+def profile_collect(lib):
+    """{kernel name: (launches, total ms)} recorded since dvs_profile_enable(1)."""
+    cap, stride = 64, 64
+    names = ctypes.create_string_buffer(cap * stride)
+    counts = (c_int * cap)()
+    ms = (c_float * cap)()
+    n = lib.dvs_profile_collect(names, stride, counts, ms, cap)
+    out = {}
+    for i in range(min(n, cap)):
+        out[names.raw[i * stride:(i + 1) * stride].split(b"\0")[0].decode()] = (int(counts[i]), float(ms[i]))
+    return out
 
 _lib = None
 

@@ -8,6 +8,67 @@
 
 static thread_local char g_err[256] = "";
 
+// ---- optional per-kernel timing (HIP events on the launch stream) -------------------------------------------------
+#include <map>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec {
+    const char* name;
+#ifndef DVS_EMU
+    hipEvent_t a, b;
+#endif
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+void dvs_prof_begin(const char* name, dvs_stream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name;
+#ifndef DVS_EMU
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, st);
+#endif
+    g_prof.push_back(r);
+}
+void dvs_prof_end(dvs_stream_t st) {
+    if (!g_prof_on) return;
+#ifndef DVS_EMU
+    (void)hipEventRecord(g_prof.back().b, st);
+#endif
+}
+extern "C" void dvs_profile_enable(int on) { g_prof_on = on != 0; }
+// Waits for the recorded events, then writes up to `cap` rows (name, launches, total milliseconds); returns the
+// number of distinct kernels and clears the record.
+extern "C" int dvs_profile_collect(char* names, int name_stride, int* counts, float* total_ms, int cap) {
+    std::map<std::string, std::pair<int, float>> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+#ifndef DVS_EMU
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+#endif
+        auto& e = agg[r.name];
+        e.first += 1;
+        e.second += ms;
+    }
+    g_prof.clear();
+    int i = 0;
+    for (auto& kv : agg) {
+        if (i >= cap) break;
+        snprintf(names + (size_t)i * name_stride, name_stride, "%s", kv.first.c_str());
+        counts[i] = kv.second.first;
+        total_ms[i] = kv.second.second;
+        ++i;
+    }
+    return (int)agg.size();
+}
+
 static int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;

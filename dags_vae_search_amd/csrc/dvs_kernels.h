@@ -103,6 +103,17 @@ void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_finalize(const FinalizeArgs& a, dvs_stream_t st);
 void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st);
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg):
+// dvs_profile_enable(1) ... launches ... dvs_profile_collect(): see include/dvs.h.
+void dvs_prof_begin(const char* name, dvs_stream_t st);
+void dvs_prof_end(dvs_stream_t st);
+#define DVS_LAUNCH(kernel, grid, block, lds, st, ...)                      \
+    do {                                                                   \
+        dvs_prof_begin(#kernel, st);                                       \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);     \
+        dvs_prof_end(st);                                                  \
+    } while (0)
+
 #ifndef DVS_EMU
 #define DVS_SET_LDS(kernel, bytes) \
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffnb_lds_floats(4) * 4;
     DVS_SET_LDS(k_ffn_bwd, lds);
-    hipLaunchKernelGGL(k_ffn_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -213,13 +213,13 @@ void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t
     const size_t bytes = lds > lds_min ? lds : lds_min;
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);
-        hipLaunchKernelGGL(k_proj_bwd<3>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(256), bytes, st, a);
     } else if (nproj == 2) {
         DVS_SET_LDS(k_proj_bwd<2>, bytes);
-        hipLaunchKernelGGL(k_proj_bwd<2>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(256), bytes, st, a);
     } else {
         DVS_SET_LDS(k_proj_bwd<1>, bytes);
-        hipLaunchKernelGGL(k_proj_bwd<1>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(256), bytes, st, a);
     }
 }
 
@@ -236,5 +236,5 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceArgs a) {
 
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st) {
     const int64_t n4 = (a.P + 3) / 4;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_reduce_slabs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a);
 }

@@ -203,5 +203,5 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attnb_lds_floats(4) * 4;
     DVS_SET_LDS(k_attn_bwd, lds);
-    hipLaunchKernelGGL(k_attn_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(256), lds, st, a);
 }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = dvs_loss_lds_floats(4, 3) * 4;
     DVS_SET_LDS(k_loss_bwd, lds);
-    hipLaunchKernelGGL(k_loss_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_loss_bwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
 void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
     const size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR + 4 * 2048 + 4 * 512) * 4;
     DVS_SET_LDS(k_embed_bwd, lds);
-    hipLaunchKernelGGL(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);
+    DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
-    hipLaunchKernelGGL(k_latent_bwd, dim3((ngroups + 3) / 4), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_latent_bwd, dim3((ngroups + 3) / 4), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -520,5 +520,5 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
 }
 
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st) {
-    hipLaunchKernelGGL(k_fc_dw, dim3(a.nslab), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_fc_dw, dim3(a.nslab), dim3(256), 0, st, a);
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
     const int threads = a.B * 16;
-    hipLaunchKernelGGL(k_pack, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_pack, dim3((threads + 255) / 256), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = emb_lds_floats() * 4;
     DVS_SET_LDS(k_embed_fwd, lds);
-    hipLaunchKernelGGL(k_embed_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attn_lds_floats() * 4;
     DVS_SET_LDS(k_attn_fwd, lds);
-    hipLaunchKernelGGL(k_attn_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffn_lds_floats() * 4;
     DVS_SET_LDS(k_ffn_fwd, lds);
-    hipLaunchKernelGGL(k_ffn_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // frag-order [B][1024] -> natural [B][16][64] (debug / tests)
@@ -405,5 +405,5 @@ __global__ void k_unfrag(const float* frag, float* out, int B) {
 }
 void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st) {
     const size_t n = (size_t)B * 1024;
-    hipLaunchKernelGGL(k_unfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frag, out, B);
+    DVS_LAUNCH(k_unfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frag, out, B);
 }

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
     const int grid = (ngroups + 3) / 4;
-    hipLaunchKernelGGL(k_latent_fwd, dim3(grid), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_latent_fwd, dim3(grid), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(LossArgs a) {
 void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = dvs_loss_lds_floats(4, 1) * 4;
     DVS_SET_LDS(k_loss_fwd, lds);
-    hipLaunchKernelGGL(k_loss_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_loss_fwd, dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -259,5 +259,5 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
 }
 
 void dvs_launch_finalize(const FinalizeArgs& a, dvs_stream_t st) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_finalize, dim3(1), dim3(256), 0, st, a);
 }

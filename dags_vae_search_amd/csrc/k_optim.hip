@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
 
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
                           float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st) {
-    hipLaunchKernelGGL(k_sqnorm, dim3(1), dim3(1024), 0, st, (const float*)grads, n, max_norm, scratch);
+    DVS_LAUNCH(k_sqnorm, dim3(1), dim3(1024), 0, st, (const float*)grads, n, max_norm, scratch);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
+    DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
                        bc1, sqrtf(bc2), (const float*)scratch);
 }

@@ -53,7 +53,7 @@ class PaceEngine:
             nbytes = self.lib.dvs_workspace_bytes(ctypes.byref(shape))
             if nbytes == 0:
                 dl.check(self.lib, 1, "dvs_workspace_bytes")
-            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            self._ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)   # slab padding must stay 0
             self._ws_batch = batch
             self._records = torch.empty(batch * dl.RECORD_BYTES, dtype=torch.uint8, device=device)
             self._status = torch.zeros(1, dtype=torch.int32, device=device)

@@ -1,0 +1,340 @@
+"""Drop-in ``PaceVaeV3`` (reference: src/encoders/pace.py:1139-2046) whose train-step arithmetic runs in
+hand-written HIP kernels (libdvs_hip.so) on MI355X.
+
+Same constructor arguments, properties, state-dict keys/shapes (108 tensors), ``loss_direct`` /
+``encode_direct`` / ``loss`` / ``encode`` / ``prepare_features`` / ``reparameterize`` signatures as the reference.
+Differences a user can observe:
+  * the model must live on a GPU for any compute (`.to("cuda")`); there is no CPU path;
+  * only the BASELINE architecture is built (embedding 32, 8 heads, 3 layers, width 64, latent 32, fc_hidden 32,
+    max_num_vertices <= 13, cardinality <= 13) — anything else raises NotImplementedError;
+  * dropout masks / reparameterisation noise come from a counter-based generator keyed by (seed, step, DAG index)
+    instead of torch's global generator (``model.seed(s)`` re-seeds it; ``eps=`` injects the noise);
+  * ``decode`` (generation, pace.py:1666-1749) is outside this path and raises NotImplementedError.
+All 108 parameters are views into ONE flat fp32 buffer (``model.flat_params``) and their gradients views into
+``model.flat_grads``: one RCCL all-reduce and one fused clip+Adam kernel cover the whole model.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib as dl
+from . import features as feat
+from .engine import PaceEngine
+
+LABEL_KEY = feat.LABEL_KEY
+POSITION_KEY = feat.POSITION_KEY
+
+
+# ---- parameter containers with the reference's module tree (names + init order => identical state dicts) -------------
+class GnnPositionalEncoding(nn.Module):          # pace.py:186-199
+    def __init__(self, ninp, dropout, max_n):
+        super().__init__()
+        self.ninp, self.max_n, self.dropout = ninp, max_n, dropout
+        self.W1 = nn.Parameter(torch.zeros(2 * max_n, 2 * ninp))
+        self.W2 = nn.Parameter(torch.zeros(2 * ninp, ninp))
+        nn.init.xavier_uniform_(self.W1.data, gain=1.414)
+        nn.init.xavier_uniform_(self.W2.data, gain=1.414)
+
+
+class _EncoderLayerParams(nn.Module):           # pace.py:17-43
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+
+
+class _DecoderLayerParams(nn.Module):           # pace.py:110-133
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm3 = nn.LayerNorm(d_model, eps=1e-5)
+
+
+class _Stack(nn.Module):                        # pace.py:70-80 / 157-161: deep copies of one initialised layer
+    def __init__(self, layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+
+class _PaceLoss(torch.autograd.Function):
+    """loss_direct as one autograd node: forward = dvs_loss_forward, backward = dvs_loss_backward."""
+
+    @staticmethod
+    def forward(ctx, model, shape, eps, *params):
+        losses = torch.zeros(4, dtype=torch.float32, device=model.flat_params.device)
+        model._engine.loss_forward(shape, model.flat_params, eps, losses)
+        model._fwd_generation += 1
+        ctx.model, ctx.shape, ctx.generation = model, shape, model._fwd_generation
+        model._last_losses = losses
+        return losses[0].clone(), losses[1].clone(), losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_total, g_recon, g_kld):
+        model = ctx.model
+        if ctx.generation != model._fwd_generation:
+            raise RuntimeError("PaceVaeV3: the saved activations of this loss were overwritten by a later forward "
+                               "(call backward() before the next loss_direct())")
+        dev = model.flat_params.device
+        z = torch.zeros((), device=dev)
+        g_total = z if g_total is None else g_total
+        g_recon = z if g_recon is None else g_recon
+        g_kld = z if g_kld is None else g_kld
+        gcoef = torch.stack([g_total + g_recon, ctx.shape.beta * g_total + g_kld]).float().contiguous()
+        flat = torch.empty_like(model.flat_params)
+        model._engine.loss_backward(ctx.shape, model.flat_params, gcoef, flat)
+        grads = [flat[off:off + n].view(shp) for (_, off, shp), n in zip(model._engine.table, model._numels)]
+        return (None, None, None, *grads)
+
+
+class PaceVaeV3(nn.Module):
+    def __init__(
+            self,
+            max_num_vertices: int,
+            vertex_label_cardinality: int,
+            vertices_embedding_size: int = 256,
+            num_heads: int = 8,
+            num_layers: int = 6,
+            ff_hidden_size: int = 512,
+            latent_layer_size: int = 64,
+            fc_hidden: int = 256,
+            dropout: float = 0.25,
+            graph_label_key: str = LABEL_KEY,
+            graph_position_key: str = POSITION_KEY,
+            graph_label_input: int = 0,
+            graph_label_output: int = 1,
+            graph_label_start: int = 2,
+    ):
+        super().__init__()
+        built = dict(vertices_embedding_size=dl.EMB, num_heads=dl.HEADS, num_layers=dl.LAYERS,
+                     ff_hidden_size=dl.D_MODEL, latent_layer_size=dl.LATENT, fc_hidden=dl.FC_HIDDEN)
+        given = dict(vertices_embedding_size=vertices_embedding_size, num_heads=num_heads, num_layers=num_layers,
+                     ff_hidden_size=ff_hidden_size, latent_layer_size=latent_layer_size, fc_hidden=fc_hidden)
+        if given != built:
+            raise NotImplementedError(f"this MI355X build implements the BASELINE architecture {built}; got {given}")
+        if max_num_vertices + 3 > dl.MAX_TOKENS or vertex_label_cardinality + 3 > 16 or max_num_vertices < 1:
+            raise NotImplementedError("this build supports max_num_vertices <= 13 and vertex_label_cardinality <= 13 "
+                                      "(one 16-token tile per DAG); larger graphs (alarm, n=37) are a later round")
+        self._max_num_vertices = max_num_vertices + 3          # pace.py:1159
+        self._vertex_label_cardinality = vertex_label_cardinality + 3
+        self.vertices_embedding_size = vertices_embedding_size
+        self.num_heads = num_heads
+        self.num_layers = num_layers
+        self.ff_hidden_size = ff_hidden_size
+        self.latent_layer_size = latent_layer_size
+        self.dropout = dropout
+        self._graph_label_key = graph_label_key
+        self._graph_position_key = graph_position_key
+        self._graph_label_input = graph_label_input
+        self._graph_label_output = graph_label_output
+        self._graph_label_start = graph_label_start
+
+        # same construction order as pace.py:1176-1207 => same initial weights under the same torch seed
+        self.vertex_position_embed = GnnPositionalEncoding(vertices_embedding_size, dropout, self.max_num_vertices)
+        self.vertex_label_embed = nn.Sequential(nn.Linear(self._vertex_label_cardinality, vertices_embedding_size),
+                                                nn.ReLU())
+        self.encoder = _Stack(_EncoderLayerParams(ff_hidden_size, num_heads, ff_hidden_size, dropout), num_layers)
+        hidden_size = self.ff_hidden_size * self.max_num_vertices
+        self.hidden_size = hidden_size
+        self.fc1 = nn.Linear(hidden_size, latent_layer_size)
+        self.fc2 = nn.Linear(hidden_size, latent_layer_size)
+        self.decoder = _Stack(_DecoderLayerParams(ff_hidden_size, num_heads, ff_hidden_size, dropout), num_layers)
+        self.add_node = nn.Sequential(nn.Linear(ff_hidden_size, fc_hidden), nn.ReLU(),
+                                      nn.Linear(fc_hidden, self._vertex_label_cardinality))
+        self.add_edge = nn.Sequential(nn.Linear(ff_hidden_size * 2, ff_hidden_size), nn.ReLU(),
+                                      nn.Linear(ff_hidden_size, 1))
+        self.fc3 = nn.Linear(latent_layer_size, hidden_size)
+
+        self._engine: Optional[PaceEngine] = None
+        self._table = None
+        self._numels: List[int] = []
+        self.flat_params: Optional[torch.Tensor] = None
+        self.flat_grads: Optional[torch.Tensor] = None
+        self._fwd_generation = 0
+        self._last_losses = None
+        self._seed = 0
+        self._step = 0
+        self.dag_offset = 0            # global index of the first DAG of the next batch (data-parallel shards)
+        self.nan_check = True          # raise ValueError on non-finite loss (pace.py:97-98), costs one host sync
+        self._flatten()
+
+    # ---- properties (pace.py:1217-1243) ------------------------------------------------------------------------
+    @property
+    def max_num_vertices(self) -> int:
+        return self._max_num_vertices
+
+    @property
+    def vertex_label_cardinality(self) -> int:
+        return self._vertex_label_cardinality
+
+    @property
+    def graph_label_key(self) -> str:
+        return self._graph_label_key
+
+    @property
+    def graph_position_key(self) -> str:
+        return self._graph_position_key
+
+    @property
+    def graph_label_input(self) -> int:
+        return self._graph_label_input
+
+    @property
+    def graph_label_output(self) -> int:
+        return self._graph_label_output
+
+    @property
+    def graph_label_start(self) -> int:
+        return self._graph_label_start
+
+    # ---- flat parameter / gradient buffers ----------------------------------------------------------------------
+    def _layout(self):
+        if self._table is None:
+            lib = dl.load()     # raises if libdvs_hip.so is missing: the model cannot exist without its kernels
+            shape = dl.make_shape(1, self._max_num_vertices, self._vertex_label_cardinality)
+            self._table, self._total = dl.param_table(lib, shape)
+            names = [n for n, _ in self.named_parameters()]
+            assert [t[0] for t in self._table] == names, "state-dict order mismatch with the C layout"
+        return self._table, self._total
+
+    def _flatten(self):
+        table, total = self._layout()
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._numels = []
+        for name, off, shp in table:
+            p = params[name]
+            n = p.numel()
+            self._numels.append(n)
+            flat[off:off + n] = p.data.reshape(-1).float()
+            p.data = flat[off:off + n].view(shp)
+            p.grad = None
+        self.flat_params = flat
+        self.flat_grads = None
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._flatten()
+        self._engine = None
+        return out
+
+    def bind_flat_grads(self) -> torch.Tensor:
+        """Allocate the flat gradient buffer and point every parameter's .grad at its slice."""
+        if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
+            self.flat_grads = torch.zeros_like(self.flat_params)
+        params = dict(self.named_parameters())
+        for (name, off, shp), n in zip(self._table, self._numels):
+            params[name].grad = self.flat_grads[off:off + n].view(shp)
+        return self.flat_grads
+
+    def _eng(self) -> PaceEngine:
+        if not self.flat_params.is_cuda:
+            raise RuntimeError("dags_vae_search_amd.PaceVaeV3 computes only on the GPU: call model.to('cuda') first "
+                               "(there is no CPU fallback)")
+        if self._engine is None:
+            self._engine = PaceEngine(self._max_num_vertices, self._vertex_label_cardinality)
+            assert self._engine.param_floats == self.flat_params.numel()
+        return self._engine
+
+    # ---- RNG ------------------------------------------------------------------------------------------------------
+    def seed(self, seed: int):
+        """Re-seed the counter-based dropout/noise generator (the analogue of torch.manual_seed for this model)."""
+        self._seed = int(seed) & 0xFFFFFFFF
+        self._step = 0
+
+    def _next_seed(self) -> int:
+        self._step += 1
+        return (self._seed << 32) | (self._step & 0xFFFFFFFF)
+
+    # ---- features (pace.py:1345-1478) ---------------------------------------------------------------------------
+    def prepare_features(self, labeled_graphs_batch, fixed_memory_len: Optional[int] = None):
+        device = self.flat_params.device
+        return feat.prepare_features(labeled_graphs_batch, self._max_num_vertices, self._vertex_label_cardinality,
+                                     self.num_heads, self._graph_label_key, self._graph_label_input,
+                                     self._graph_label_output, self._graph_label_start, fixed_memory_len, device)
+
+    def _pack(self, features: Dict):
+        eng = self._eng()
+        dev = self.flat_params.device
+        f = {k: features[k].to(dev) for k in ("vertex_label_features", "vertex_position_features",
+                                              "adjacency_matrices", "target_masks")}   # pace.py:1981-1984
+        eng.pack(f, check=self.nan_check)
+        return f["vertex_label_features"].shape[0]
+
+    def _shape(self, batch: int, beta: float):
+        return self._eng().shape(batch, training=self.training, dropout=self.dropout, beta=beta, eps_scale=0.01,
+                                 dag_offset=self.dag_offset, seed=self._next_seed() if self.training else 0)
+
+    # ---- encode (pace.py:1613-1647) -----------------------------------------------------------------------------
+    def encode_direct(self, features: Dict) -> Tuple[torch.Tensor, torch.Tensor]:
+        B = self._pack(features)
+        dev = self.flat_params.device
+        mu = torch.empty(B, self.latent_layer_size, device=dev)
+        logvar = torch.empty(B, self.latent_layer_size, device=dev)
+        shape = self._shape(B, 0.005)
+        self._engine.encode(shape, self.flat_params, mu, logvar)
+        self._fwd_generation += 1
+        return mu, logvar
+
+    def encode(self, labeled_graphs_batch) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.encode_direct(self.prepare_features(labeled_graphs_batch))
+
+    def reparameterize(self, mu: torch.Tensor, log_var: torch.Tensor, epsilon_scale: float = 0.01) -> torch.Tensor:
+        if self.training:                                    # pace.py:1659-1664
+            std = torch.exp(0.5 * log_var)
+            return mu + torch.randn_like(std) * epsilon_scale * std
+        return mu
+
+    def decode(self, z: torch.Tensor):
+        raise NotImplementedError("decode() (sequential generation, pace.py:1666-1749) is not on the train-step hot "
+                                  "path built in this round (SURVEY.md §8f item 2)")
+
+    # ---- loss (pace.py:1974-2046) -------------------------------------------------------------------------------
+    def loss_direct(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None):
+        """(total, recon, kld) as 0-d tensors attached to the autograd graph of the 108 parameters.
+        ``eps`` (optional, [B, latent], already multiplied by epsilon_scale) injects the reparameterisation noise."""
+        B = self._pack(features)
+        shape = self._shape(B, beta)
+        if eps is not None:
+            eps = eps.to(self.flat_params.device, torch.float32).contiguous()
+        total, recon, kld = _PaceLoss.apply(self, shape, eps, *self.parameters())
+        if self.nan_check and bool(self._last_losses[3].item() != 0.0):
+            raise ValueError("NaN detected in the output of the PACE-VAE step")        # pace.py:98
+        return total, recon, kld
+
+    def loss(self, labeled_graphs_batch, beta: float = 0.005):
+        return self.loss_direct(self.prepare_features(labeled_graphs_batch), beta)
+
+    # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
+    def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
+                      packed: bool = False) -> torch.Tensor:
+        """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
+        [total, recon, kld, non-finite flag]; nothing is synchronised."""
+        eng = self._eng()
+        if not packed:
+            self._pack(features)
+        B = eng._ws_batch
+        shape = self._shape(B, beta)
+        losses = torch.zeros(4, dtype=torch.float32, device=self.flat_params.device)
+        eng.loss_forward(shape, self.flat_params, eps, losses)
+        self._fwd_generation += 1
+        grads = self.bind_flat_grads()
+        if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
+            self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
+            self._gcoef_beta = beta
+        eng.loss_backward(shape, self.flat_params, self._gcoef, grads)
+        return losses

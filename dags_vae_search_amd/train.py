@@ -1,0 +1,99 @@
+"""Train-step API of the reference, MI355X-native underneath.
+
+Mirrors ``train_batch`` (experiments/03_synthetic_12/main.py:95-118; API twin src/train_model.py:18-28),
+``load_model_state`` (src/train_utils.py:11-36), ``collate_graph_batch`` (src/train_utils.py:39-40),
+``pace_collate_fn`` (main.py:75-92) and the epoch loop semantics of ``train_model`` (main.py:175-193).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from typing import Dict, Iterable, Optional
+
+import torch
+from torch.nn.utils import clip_grad_norm_
+
+from .features import collate_graph_batch, pace_collate_fn  # noqa: F401  (re-exported, reference names)
+from .optim import Adam as FusedAdam
+
+
+def load_model_state(model, state_name):
+    """src/train_utils.py:11-36: load the checkpoint entries whose keys exist in the model (weights only)."""
+    pretrained = torch.load(state_name, map_location="cpu", weights_only=True)
+    model_dict = model.state_dict()
+    pretrained = {k: v for k, v in pretrained.items() if k in model_dict}
+    model.load_state_dict(pretrained, strict=False) if len(pretrained) != len(model_dict) else \
+        model.load_state_dict(pretrained)
+    return
+
+
+def _to_device(batch: Dict, device) -> Dict:
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
+    """One train step: loss_direct -> backward -> clip_grad_norm_ -> optimizer.step (main.py:95-118).
+
+    Returns ``(loss_value: float, recon, kld)`` like the reference.  With the fused optimiser
+    (``dags_vae_search_amd.optim.Adam``) the step runs without an autograd graph: forward+backward kernels write the
+    flat gradient, ``group`` (a torch.distributed process group, or True for the default one) SUM-all-reduces it over
+    RCCL, and one fused kernel pair clips and applies Adam.  With any other optimiser the reference sequence runs on
+    top of the autograd-wrapped kernels (parameters are ordinary leaf tensors with .grad)."""
+    model.train()
+    optimizer.zero_grad()
+    if isinstance(optimizer, FusedAdam):
+        if optimizer._model is None:
+            optimizer.attach(model)
+        losses = model.loss_and_grad(batch)
+        if group is not None:
+            import torch.distributed as dist
+            pg = None if group is True else group
+            dist.all_reduce(model.flat_grads, op=dist.ReduceOp.SUM, group=pg)       # SUM, then clip
+            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=pg)
+        optimizer.step(max_grad_norm=max_grad_norm)
+        host = losses.tolist()                                                      # the step's only host sync
+        if host[3] != 0.0:
+            raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
+        return host[0], losses[1], losses[2]
+    loss, recon, kld = model.loss_direct(batch)
+    loss_value = loss.item()
+    loss.backward()
+    if group is not None:
+        import torch.distributed as dist
+        pg = None if group is True else group
+        for p in model.parameters():
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=pg)
+    clip_grad_norm_(model.parameters(), max_grad_norm)
+    optimizer.step()
+    return loss_value, recon, kld
+
+
+def train_model(model, dataset, epochs: int = 1, batch_size: int = 32, lr: float = 1e-4, max_grad_norm: float = 1.0,
+                checkpoint_dir: Optional[str] = None, seed: int = 42, fused: bool = True, log=print):
+    """Epoch loop with the reference's semantics (main.py:121-198): seeds 42, shuffle every epoch, Adam lr 1e-4,
+    ReduceLROnPlateau('min', 0.1, patience 10) stepped on the LAST batch's loss, state_dict saved per epoch."""
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    from torch.utils.data import DataLoader
+    torch.manual_seed(seed)
+    model.seed(seed)
+    dl = DataLoader(dataset=dataset, batch_size=batch_size, collate_fn=pace_collate_fn, shuffle=True)
+    optimizer = (FusedAdam(model.parameters(), lr=lr).attach(model) if fused
+                 else torch.optim.Adam(model.parameters(), lr=lr))
+    scheduler = ReduceLROnPlateau(optimizer, "min", factor=0.1, patience=10)
+    device = model.flat_params.device
+    loss_value = math.inf
+    t0 = time.time()
+    history = []
+    for epoch in range(1, epochs + 1):
+        model.train()
+        for batch in dl:
+            loss_value, recon, kld = train_batch(_to_device(batch, device), model, optimizer, max_grad_norm)
+        scheduler.step(loss_value)
+        history.append(loss_value / batch_size)
+        log("====> Epoch: {0} loss: {1:.4f}, compute time: {2:.4f}".format(epoch, loss_value / batch_size,
+                                                                         time.time() - t0))
+        if checkpoint_dir:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(checkpoint_dir, "model_checkpoint_{}.pth".format(epoch)))
+    return history

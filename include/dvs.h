@@ -91,6 +91,13 @@ int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float*
                   float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
                   void* stream);
 
+/* Optional per-kernel timing for the benchmark's roofline leg: while enabled, every kernel launch is bracketed by
+ * HIP events recorded on its own stream; dvs_profile_collect waits for them and returns, per kernel name, the
+ * number of launches and their summed duration in milliseconds (rows of `name_stride` chars).  Process-global
+ * debug state; leave disabled in production. */
+void dvs_profile_enable(int on);
+int dvs_profile_collect(char* names, int name_stride, int* counts, float* total_ms, int cap);
+
 /* Debug/test access: copy saved activation `slot` (natural [B,16,64] layout) out of the workspace. */
 int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream);
 

@@ -27,10 +27,21 @@ def gpu_forward(cfg, params, graphs, training=False, dropout=0.15, eps=None, see
 
 
 def smoke_check():
+    """One tiny train-mode forward+backward of the hot path (8 DAGs, n=12) on cuda:0, checked against the oracle."""
+    from dags_vae_search_amd import LabeledGraph, PaceVaeV3
     cfg, params, graphs, z = load_golden("n12c12")
     graphs = graphs[:8]
-    eng, flat, shape, losses, mu, lv, f_np = gpu_forward(cfg, params, graphs)
-    with torch.no_grad():
-        total, recon, kld = po.loss_direct(params, cfg, ofeat.to_torch(f_np), training=False)
-    assert rel(losses[0], total) < 1e-4, (losses, float(total))
-    assert rel(losses[2], kld) < 1e-4
+    model = PaceVaeV3(12, 12, 32, 8, 3, 64, 32, 32, 0.0)
+    model.load_state_dict(params)
+    model = model.to("cuda:0").train()
+    eps = torch.from_numpy(z["train0/eps"][:8])
+    total, recon, kld = model.loss_direct(model.prepare_features([LabeledGraph(l, e) for l, e in graphs]), eps=eps)
+    total.backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    cfg0 = po.PaceConfig(n=12, card=12, dropout=0.0)
+    t, r, k = po.loss_direct(P, cfg0, ofeat.to_torch(ofeat.dense_features(graphs, 12)), training=True, eps=eps)
+    t.backward()
+    assert rel(total.item(), t.detach()) < 1e-4, (total.item(), float(t))
+    for name, p in model.named_parameters():
+        ref = P[name].grad
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * max(ref.abs().max().item(), 1e-3), name

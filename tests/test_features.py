@@ -1,0 +1,66 @@
+"""Host logic: the product's igraph-free feature front-end vs the oracle restatement and reference fixtures (CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from dags_vae_search_amd import features as pf
+from oracle import features as ofeat
+from tests.helpers import graphs_from, load_npz
+
+
+def test_row_codec_and_validation():
+    tk = pf.LabeledDag(num_vertices=5, label_cardinality=5)
+    row = {"l0": 0, "l1": 1, "l2": 2, "l3": 3, "l4": 4, "e0": "", "e1": "1", "e2": "11", "e3": "001", "e4": "0001"}
+    g = tk.from_dict_to_graph(row)                    # reference fixture tests/toolkit/test_labeled.py:49-64
+    assert g.labels == [0, 1, 2, 3, 4] and g.edges == [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4)]
+    assert tk.from_graph_to_dict_writable(g) == row
+    assert tk.is_valid_dict(row) and not tk.is_valid_dict({**row, "l4": 7})
+    with pytest.raises(ValueError):
+        tk.from_dict_to_graph({**row, "e3": "01"})
+    with pytest.raises(AssertionError):
+        tk.from_dict_to_graph({**row, "l0": 9})
+
+
+def test_pace_wrapping_fixture():
+    # reference fixture tests/models/test_pace_utils.py:18-61
+    pl, child, pos = pf.pace_arrays([0, 1, 2, 3, 4], [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4)], 8)
+    assert list(pl) == [2, 0, 3, 4, 5, 6, 7, 1] and list(pos) == list(range(8))
+    edges = sorted((u, v) for u in range(8) for v in range(8) if (child[u] >> v) & 1)
+    assert edges == sorted([(0, 1), (1, 2), (2, 3), (2, 4), (3, 4), (4, 5), (5, 6), (6, 7)])
+    with pytest.raises(AssertionError):
+        pf.pace_arrays([0, 1, 2], [], 8)
+
+
+@pytest.mark.parametrize("n,card,seed", [(8, 8, 1), (12, 12, 2), (12, 1, 3), (11, 11, 4), (5, 3, 5)])
+def test_prepare_features_matches_oracle(n, card, seed):
+    graphs = ofeat.synthetic_dags(n, card, 40, seed=seed)
+    ref = ofeat.dense_features(graphs, card)
+    got = pf.prepare_features([pf.LabeledGraph(l, e) for l, e in graphs], n + 3, card + 3)
+    for k, v in ref.items():
+        if isinstance(v, np.ndarray):
+            assert got[k].dtype == torch.from_numpy(v).dtype, k
+            assert np.array_equal(got[k].numpy(), v), k
+        else:
+            assert got[k] == v, k
+
+
+def test_prepare_features_on_known_answer_graphs_and_collate():
+    z = load_npz("asia_known_answer.npz")
+    graphs = graphs_from(z, 8)[:64]
+    one = [pf.prepare_features([g], 11, 11) for g in graphs]
+    batch = pf.pace_collate_fn(one)
+    ref = ofeat.dense_features(graphs, 8)
+    for k in ("vertex_label_features", "vertex_position_features", "adjacency_matrices", "target_masks",
+              "source_masks", "memory_masks"):
+        assert np.array_equal(batch[k].numpy(), ref[k]), k
+    assert batch["vertex_labels"] == ref["vertex_labels"] and batch["num_vertices"] == ref["num_vertices"]
+    # diagonal never masked (no fully-masked attention rows -> no NaN)
+    tm = batch["target_masks"].numpy()
+    assert not tm[:, np.arange(11), np.arange(11)].any()
+
+
+def test_product_synthetic_generator_matches_oracle_copy():
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    a = synthetic_dags(12, 12, 32, seed=9)
+    b = ofeat.synthetic_dags(12, 12, 32, seed=9)
+    assert [(g.labels, g.edges) for g in a] == [(l, e) for l, e in b]

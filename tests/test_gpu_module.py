@@ -1,0 +1,174 @@
+"""GPU parity through the drop-in Python surface (PaceVaeV3 / train_batch) -> C ABI -> HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features as ofeat
+from oracle import pace_oracle as po
+from oracle.rng import DeviceMasks
+from tests.helpers import CONFIGS, grad_err, graphs_from, load_golden, load_npz, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build_model(cfg, params, dropout=0.15):
+    from dags_vae_search_amd import PaceVaeV3
+    m = PaceVaeV3(max_num_vertices=cfg.n, vertex_label_cardinality=cfg.card, vertices_embedding_size=32, num_heads=8,
+                  num_layers=3, ff_hidden_size=64, latent_layer_size=32, fc_hidden=32, dropout=dropout)
+    m.load_state_dict(params)
+    return m.to(DEV)
+
+
+def feats_for(model, graphs):
+    from dags_vae_search_amd import LabeledGraph
+    return model.prepare_features([LabeledGraph(l, e) for l, e in graphs])
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_loss_direct_and_autograd_match_reference_golden(name):
+    cfg, params, graphs, z = load_golden(name)
+    model = build_model(cfg, params).eval()
+    total, recon, kld = model.loss_direct(feats_for(model, graphs))
+    assert rel(total.item(), z["eval/total"]) < 1e-4            # BASELINE.json: ELBO < 1e-4 relative
+    assert rel(kld.item(), z["eval/kld"]) < 1e-4
+    assert abs(recon.item() - float(z["eval/recon"])) < 1e-4 * max(1.0, abs(float(z["eval/recon"])))
+    total.backward()
+    err, worst = grad_err({k: p.grad for k, p in model.named_parameters()}, z, "eval/grad/")
+    assert err < 2e-3, (worst, err)
+
+
+@pytest.mark.parametrize("name", ["n12c12", "asia_rand"])
+def test_train_mode_dropout0_injected_eps_and_one_step(name):
+    """train mode, dropout 0, reference's captured eps -> golden loss/gradients, then golden clip+Adam step, through
+    BOTH optimiser paths: stock torch.optim.Adam over the autograd-wrapped kernels and the fused flat-buffer Adam."""
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.train import train_batch
+    cfg, params, graphs, z = load_golden(name)
+    eps = torch.from_numpy(z["train0/eps"])
+    gn = np.sqrt(sum(float((z[k].astype(np.float64) ** 2).sum()) for k in z.files if k.startswith("train0/grad/")))
+    coef = min(1.0, 1.0 / (gn + 1e-6))
+
+    def check_step(model):
+        worst_big = 0.0
+        for k, p in model.state_dict().items():
+            err = np.abs(p.cpu().numpy() - z["step/param/" + k])
+            big = np.abs(z["train0/grad/" + k]) * coef > 1e-5
+            assert err.max() < 3e-5, k
+            if big.any():
+                worst_big = max(worst_big, float(err[big].max()))
+        assert worst_big < 1e-6
+
+    # (a) reference sequence with a stock optimiser
+    model = build_model(cfg, params, dropout=0.0).train()
+    f = feats_for(model, graphs)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt.zero_grad()
+    total, recon, kld = model.loss_direct(f, eps=eps)
+    assert rel(total.item(), z["train0/total"]) < 1e-4
+    total.backward()
+    err, worst = grad_err({k: p.grad for k, p in model.named_parameters()}, z, "train0/grad/")
+    assert err < 2e-3, (worst, err)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    check_step(model)
+    # (b) fused path
+    model2 = build_model(cfg, params, dropout=0.0).train()
+    fo = dopt.Adam(model2.parameters(), lr=1e-4).attach(model2)
+    losses = model2.loss_and_grad(f, eps=eps.to(DEV))
+    fo.step(max_grad_norm=1.0)
+    assert rel(losses[0].item(), z["train0/total"]) < 1e-4
+    assert abs(fo.grad_norm.item() - gn) / gn < 1e-4
+    check_step(model2)
+
+
+@pytest.mark.parametrize("name,B", [("n12c12", 48), ("asia_rand", 32)])
+def test_train_mode_dropout_on_matches_oracle_with_device_masks(name, B):
+    cfg, params, graphs, z = load_golden(name)
+    graphs = graphs[:B]
+    model = build_model(cfg, params, dropout=0.15).train()
+    model.seed(77)
+    model.dag_offset = 5
+    f = feats_for(model, graphs)
+    total, recon, kld = model.loss_direct(f)
+    total.backward()
+    seed = (77 << 32) | 1                                  # PaceVaeV3._next_seed: (seed << 32) | step
+    masks = DeviceMasks(seed, 0.15, dag_offset=5)
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f_np = ofeat.dense_features(graphs, cfg.card)
+    t, r, k = po.loss_direct(P, cfg, ofeat.to_torch(f_np), training=True, eps=torch.from_numpy(masks.eps(B)), masks=masks)
+    t.backward()
+    assert rel(total.item(), t.detach()) < 1e-4 and rel(kld.item(), k.detach()) < 1e-4
+    scale = max(float(p.grad.abs().max()) for p in P.values())
+    for kname, p in model.named_parameters():
+        ref = P[kname].grad.numpy()
+        e = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale)
+        assert e < 3e-3, (kname, e)
+
+
+def test_encode_direct_known_answer():
+    """254 (graph -> mu) rows written by the reference's own pipeline (experiments/01_bn_asia predictor dataset)."""
+    z = load_npz("asia_known_answer.npz")
+    ck = load_npz("asia_ckpt110.npz")
+    cfg = po.PaceConfig(n=8, card=8)
+    model = build_model(cfg, {k: torch.from_numpy(ck[k]) for k in ck.files}).eval()
+    mu, logvar = model.encode_direct(feats_for(model, graphs_from(z, 8)))
+    assert np.abs(mu.cpu().numpy() - z["mu"]).max() < 1e-5
+
+
+def test_errors_are_loud():
+    from dags_vae_search_amd import LabeledGraph, PaceVaeV3
+    cfg, params, graphs, z = load_golden("asia")
+    model = build_model(cfg, params).eval()
+    f = feats_for(model, graphs[:4])
+    bad = dict(f)
+    bad["vertex_label_features"] = f["vertex_label_features"] * 0.5
+    with pytest.raises(ValueError):
+        model.loss_direct(bad)
+    with pytest.raises(AssertionError):
+        model.prepare_features([LabeledGraph([0, 1, 2], [(0, 1)])])
+    cpu_model = PaceVaeV3(8, 8, 32, 8, 3, 64, 32, 32, 0.15)
+    with pytest.raises(RuntimeError):
+        cpu_model.loss_direct({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()})
+    with pytest.raises(NotImplementedError):
+        PaceVaeV3(37, 37, 32, 8, 3, 64, 32, 32, 0.15)
+    with pytest.raises(NotImplementedError):
+        PaceVaeV3(8, 8)                      # reference defaults (256-wide, 6 layers) are not this build
+
+
+def test_full_size_properties_n12_b4096():
+    """BASELINE metric shape (n=12, card=12, B=4096): size-independent properties instead of an oracle run:
+    shard additivity of loss and gradient (the data-parallel contract), bitwise run-to-run determinism, and
+    training steps that reduce the loss."""
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.dist import shard_features
+    from dags_vae_search_amd.train import train_batch
+    cfg = po.PaceConfig(n=12, card=12)
+    params = po.init_params(cfg, seed=3)
+    graphs = ofeat.synthetic_dags(12, 12, 4096, seed=42)
+    model = build_model(cfg, params).train()
+    f = feats_for(model, graphs)
+    model.seed(1)
+    l1 = model.loss_and_grad(f).clone()
+    g1 = model.flat_grads.clone()
+    model.seed(1)
+    l2 = model.loss_and_grad(f).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, model.flat_grads)          # deterministic, no float atomics
+    tot = torch.zeros_like(g1)
+    lsum = 0.0
+    for rank in range(2):
+        shard, off = shard_features(f, rank, 2)
+        model.seed(1)
+        model.dag_offset = off
+        ls = model.loss_and_grad(shard)
+        tot += model.flat_grads
+        lsum += ls[0].item()
+    model.dag_offset = 0
+    assert rel(lsum, l1[0].item()) < 1e-5
+    assert (tot - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
+    opt = dopt.Adam(model.parameters(), lr=1e-3).attach(model)
+    first = None
+    for step in range(12):
+        loss_value, recon, kld = train_batch(f, model, opt)
+        first = loss_value if first is None else first
+    assert np.isfinite(loss_value) and loss_value < 0.97 * first

@@ -68,11 +68,32 @@ def make_batch(batch: int, seed: int, device):
     return graphs, feats, dev_feats
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box gives a
+    16-core share of a much larger host; os.cpu_count() there reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
 def cpu_baseline(graphs, feats, steps: int = 3):
-    """Reference CPU path = oracle port of train_batch (train mode, dropout 0.15, Adam), all host cores."""
+    """Reference CPU path = oracle port of train_batch (train mode, dropout 0.15, Adam), all usable host cores."""
     from oracle import pace_oracle as po
-    cores = os.cpu_count() or 1
+    cores = min(host_cores(), 32)
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
     cfg = po.PaceConfig(n=N_VERT, card=CARD)
     torch.manual_seed(42)
     tr = po.OracleTrainer(cfg, po.init_params(cfg, seed=42))
@@ -113,6 +134,7 @@ def main():
     from dags_vae_search_amd import _lib as dl
     from dags_vae_search_amd.train import train_batch
 
+    torch.set_num_threads(min(host_cores(), 16))
     torch.manual_seed(42)          # experiments/03_synthetic_12/main.py:122-124: same initial weights on every rank
     model = PaceVaeV3(max_num_vertices=N_VERT, vertex_label_cardinality=CARD, vertices_embedding_size=32, num_heads=8,
                       num_layers=3, ff_hidden_size=64, latent_layer_size=32, fc_hidden=32, dropout=0.15).to(device)
@@ -130,9 +152,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("inputs ready; warm-up")
     for _ in range(args.warmup):
         step()
     sync()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss_value, _, _ = step()
@@ -146,6 +170,7 @@ def main():
     global_batch = args.batch * world
     value = global_batch * args.steps / dt
 
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     # ---- per-kernel durations (HIP events on the launch stream), separate untimed steps --------------------------------
     lib = dl.load()
     lib.dvs_profile_enable(1)

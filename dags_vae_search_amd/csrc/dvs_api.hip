@@ -207,6 +207,7 @@ DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab) {
     w.gz = take((size_t)B * 64);
     w.nslab = nslab;
     w.slabs = take((size_t)nslab * (size_t)P);
+    w.fcpart = take((size_t)DVS_FC_PARTS * (size_t)P);
     w.total_floats = off;
     return w;
 }
@@ -240,9 +241,9 @@ static DvsDims make_dims(const dvs_shape* s) {
     return d;
 }
 
-static int grid_for(int B) {
+static int grid_for(int B) {   // forward kernels: 8 waves (512 threads) per workgroup, one DAG per wave at a time
     const int cus = dvs_device_cus();
-    const int want = (B + 3) / 4;
+    const int want = (B + 7) / 8;
     const int cap = cus > 0 ? cus : 256;
     return want < cap ? want : cap;
 }

@@ -69,17 +69,18 @@ struct FcDwArgs {
     const float* xenc;           // [B][1024]
     const float* gmem;           // [B][1024]
     const float* z;              // [B][32]
-    float* slab;
+    float* fcpart;               // [DVS_FC_PARTS][P]: per-batch-quarter partials of the fc1/fc2/fc3 gradients
     int64_t P;
-    int nslab;
     int64_t o_fc1_w, o_fc1_b, o_fc2_w, o_fc2_b, o_fc3_w, o_fc3_b;
 };
 
 struct ReduceArgs {
-    const float* slab;
+    const float* slab;           // [nslab][P] per-workgroup partials (all parameters except fc1/fc2/fc3)
+    const float* fcpart;         // [DVS_FC_PARTS][P] partials of fc1/fc2 (offsets [fc_lo1, fc_hi1)) and fc3 ([fc_lo2, fc_hi2))
     float* grads;
     int64_t P;
     int nslab;
+    int64_t fc_lo1, fc_hi1, fc_lo2, fc_hi2;
 };
 
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st);
@@ -100,7 +101,7 @@ size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave);
 // Must be called by ALL threads of the workgroup (contains barriers).
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_reduce_dw(float* buf, const f4 (&dw)[OT][IT], float* dst, const Lane& L,
-                                              int rows = 16 * OT, int ld_dst = 16 * IT) {
+                                              int rows = 16 * OT, int ld_dst = 16 * IT, int cols_used = 16 * IT) {
     constexpr int COLS = 16 * IT;
     for (int w = 0; w < L.nwaves; ++w) {
         if (L.wave == w) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void dvs_reduce_dw(float* buf, const f4 (&dw)[OT][IT]
     }
     for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
         const int row = i / COLS, col = i - row * COLS;
-        dst[(size_t)row * ld_dst + col] = buf[i];
+        if (col < cols_used) dst[(size_t)row * ld_dst + col] = buf[i];
     }
     __syncthreads();
 }

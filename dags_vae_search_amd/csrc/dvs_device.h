@@ -113,60 +113,56 @@ __device__ __forceinline__ f4 dvs_vecT(const float* v, int t, const Lane& L) { r
 // y^T[OT] (T) += W[row0 + 16*OT rows][16*IT cols] * x^T[IT] (T)
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_mat_T(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
+    // contraction step (t,kk) outermost, output tile innermost: OT independent accumulator chains are in flight, so the
+    // 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue rate
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-        f4 acc = y[ot];
+    for (int t = 0; t < IT; ++t) {
+        f4 w[OT];
 #pragma unroll
-        for (int t = 0; t < IT; ++t) {
-            const f4 w = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+        for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(w[kk], x[t][kk], acc);
-        }
-        y[ot] = acc;
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(w[ot][kk], x[t][kk], y[ot]);
     }
 }
 // y[OT] (N) += x (T regs used as A) * W^T : y[dt][reg] = Y[token 4g+reg][16dt + r]
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_mat_N(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-        f4 acc = y[ot];
+    for (int t = 0; t < IT; ++t) {
+        f4 w[OT];
 #pragma unroll
-        for (int t = 0; t < IT; ++t) {
-            const f4 w = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+        for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(x[t][kk], w[kk], acc);
-        }
-        y[ot] = acc;
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(x[t][kk], w[ot][kk], y[ot]);
     }
 }
 // dx^T[IT] (T) += W^T * dy^T[OT] (T), W = [16*OT rows (row0..)][16*IT cols]
 template <int IT, int OT>
 __device__ __forceinline__ void dvs_mat_Tt(f4 (&dx)[IT], const f4 (&dy)[OT], const float* W, int ld, int row0, const Lane& L) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        f4 acc = dx[it];
+    for (int ot = 0; ot < OT; ++ot) {
+        f4 w[IT];
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-            const f4 w = dvs_wcol(W + row0 * ld, ld, 16 * it, ot, L);
+        for (int it = 0; it < IT; ++it) w[it] = dvs_wcol(W + row0 * ld, ld, 16 * it, ot, L);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(w[kk], dy[ot][kk], acc);
-        }
-        dx[it] = acc;
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) dx[it] = dvs_mfma(w[it][kk], dy[ot][kk], dx[it]);
     }
 }
 // dW[ot][it] += dY(N)[ot]^T (x) X(N)[it] over this DAG's 16 tokens; D = dW[16ot + 4g + reg][16it + r]
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_outer_acc(f4 (&dw)[OT][IT], const f4 (&dyN)[OT], const f4 (&xN)[IT]) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            f4 acc = dw[ot][it];
+        for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = dvs_mfma(dyN[ot][kk], xN[it][kk], acc);
-            dw[ot][it] = acc;
-        }
+            for (int it = 0; it < IT; ++it) dw[ot][it] = dvs_mfma(dyN[ot][kk], xN[it][kk], dw[ot][it]);
 }
 
 // ---- T <-> N transposes through the wave's private scratch tile [16][DVS_LD] ---------------------------------

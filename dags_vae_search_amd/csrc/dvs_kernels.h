@@ -171,3 +171,61 @@ __device__ __forceinline__ void dvs_store_pre(float* out_pre, float* out_stats, 
         out_stats[dag * 32 + 16 + L.r] = rstd;
     }
 }
+
+// ---- embedding selectors -----------------------------------------------------------------------------------------
+// The positional encoder's first layer acts on one-hot rows, i.e. it gathers rows of W1 (pace.py:214-215):
+//   e1pre[i] = W1[pos_i] + sum_{j parent of i} W1[N + pos_j]
+// Written as products with two 0/1 selector matrices over positions p, Sel[p][i] = [pos_i == p] and
+// Par[p][i] = [the vertex at position p is a parent of i], both the gather (forward) and its scatter (weight
+// gradient) are MFMA chains: e1pre^T = W1a^T Sel + W1b^T Par ; dW1a = Sel de1 ; dW1b = Par de1.
+// selB/parB: B-operand form [k <-> p = 4g+kk][col i = r]; selA/parA: A-operand form [row p = r][k <-> i = 4g+kk].
+constexpr int EMB_LDW2 = 36;
+struct EmbSel {
+    f4 selB, parB, selA, parA, labA;   // labA: [k <-> i = 4g+kk][col c = r] = [label_i == c] (B-operand of the label scatter)
+};
+__device__ __forceinline__ EmbSel dvs_emb_selectors(const DvsRecord* rec, int N, float* scr, const Lane& L) {
+    int* inv = (int*)scr;                              // inv[p] = vertex at position p
+    if (L.g == 0) inv[L.r] = 0;
+    dvs_wave_sync();
+    const int pos_r = rec->pos[L.r];
+    if (L.g == 0 && L.r < N) inv[pos_r] = L.r;
+    dvs_wave_sync();
+    const unsigned par_r = rec->parents[L.r];
+    const int inv_r = inv[L.r];
+    EmbSel s;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int p = 4 * L.g + kk;                    // as position index (B forms) and as token index (A forms)
+        const bool vr = L.r < N, vp = p < N;
+        s.selB[kk] = (vr && pos_r == p) ? 1.f : 0.f;
+        s.parB[kk] = (vr && vp && ((par_r >> inv[p]) & 1u)) ? 1.f : 0.f;
+        s.selA[kk] = (vp && rec->pos[p] == L.r) ? 1.f : 0.f;
+        s.parA[kk] = (vp && vr && ((rec->parents[p] >> inv_r) & 1u)) ? 1.f : 0.f;
+        s.labA[kk] = (vp && rec->label[p] == L.r) ? 1.f : 0.f;
+    }
+    dvs_wave_sync();
+    return s;
+}
+// hidden of the positional encoder, T-layout [64 x tok], post-ReLU, before dropout.  W1: LDS image [32][DVS_LD] whose
+// rows >= 2N are zero.
+__device__ __forceinline__ void dvs_emb_hidden(f4 (&e1)[4], const float* W1, int N, const EmbSel& s, const Lane& L) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) e1[ct] = f4_zero();
+    f4 wa[4], wb[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        wa[ct] = dvs_wcol(W1, DVS_LD, 16 * ct, 0, L);
+        wb[ct] = dvs_wcol(W1 + N * DVS_LD, DVS_LD, 16 * ct, 0, L);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            e1[ct] = dvs_mfma(wa[ct][kk], s.selB[kk], e1[ct]);
+            e1[ct] = dvs_mfma(wb[ct][kk], s.parB[kk], e1[ct]);
+        }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) e1[ct][kk] = fmaxf(e1[ct][kk], 0.f);
+}

@@ -229,8 +229,19 @@ void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t
 __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceArgs a) {
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= a.P) return;
+    const bool fc = (i4 >= a.fc_lo1 && i4 < a.fc_hi1) || (i4 >= a.fc_lo2 && i4 < a.fc_hi2);
+    const float* src = fc ? a.fcpart : a.slab;
+    const int n = fc ? DVS_FC_PARTS : a.nslab;
     f4 s = f4_zero();
-    for (int k = 0; k < a.nslab; ++k) s += *(const f4*)(a.slab + (size_t)k * a.P + i4);
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {      // 8 independent 16-byte loads in flight per lane
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f4*)(src + (size_t)(k + u) * a.P + i4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < n; ++k) s += *(const f4*)(src + (size_t)k * a.P + i4);
     *(f4*)(a.grads + i4) = s;
 }
 

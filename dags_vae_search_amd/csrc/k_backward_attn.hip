@@ -25,25 +25,28 @@ __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
 }
 static size_t attnb_lds_floats(int nwaves) { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)nwaves * DVS_SCR; }
 
-__device__ __forceinline__ f4 drop_T(f4 p, uint32_t key, int h, const DvsDrop& D, const Lane& L) {
-    if (!D.on) return p;
+// dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
+// reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
+__device__ __forceinline__ f4 mask_T(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return f4_splat(1.f);
     const uint32_t p0 = (uint32_t)((h * 16 + L.r) * 8 + 2 * L.g);
     const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
-    p[0] = ((h0 & 0xFFFFu) >= D.thr16) ? p[0] * D.scale : 0.f;
-    p[1] = ((h0 >> 16) >= D.thr16) ? p[1] * D.scale : 0.f;
-    p[2] = ((h1 & 0xFFFFu) >= D.thr16) ? p[2] * D.scale : 0.f;
-    p[3] = ((h1 >> 16) >= D.thr16) ? p[3] * D.scale : 0.f;
-    return p;
+    f4 m;
+    m[0] = ((h0 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[1] = ((h0 >> 16) >= D.thr16) ? D.scale : 0.f;
+    m[2] = ((h1 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[3] = ((h1 >> 16) >= D.thr16) ? D.scale : 0.f;
+    return m;
 }
-// same mask in the S orientation: register reg holds (i = 4g+reg, j = r) -> element ((h*16+i)*16 + j)
-__device__ __forceinline__ f4 drop_S(f4 p, uint32_t key, int h, const DvsDrop& D, const Lane& L) {
-    if (!D.on) return p;
+__device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return f4_splat(1.f);
+    f4 m;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const uint32_t e = (uint32_t)((h * 16 + 4 * L.g + reg) * 16 + L.r);
-        p[reg] = dvs_dropout_elem(p[reg], key, e, D);
+        m[reg] = dvs_dropout_elem(1.0f, key, e, D);
     }
-    return p;
+    return m;
 }
 
 __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
@@ -112,79 +115,153 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
         dvs_t2n<4>(dON, dOT, scr, L);
 
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
-        unsigned al4[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
-
+        const bool g0 = (L.g >> 1) == 0, r0 = (L.r >> 3) == 0;
         f4 oN[4], dq[4], dk[4], dv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) oN[t] = dq[t] = dk[t] = dv[t] = f4_zero();
+        // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) ------------------------------------------------
+        f4 pT[8], dsT[8];
+        float lse[8], delta[8];
+        {
+            f4 sT[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int h = 0; h < 8; ++h) sT[h] = f4_zero();
 #pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-                const int h = 2 * t + hs;
-                const bool mine_g = (L.g >> 1) == hs, mine_r = (L.r >> 3) == hs;
-                // ---- T orientation ------------------------------------------------------------------------
-                f4 s = f4_zero();
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) s = dvs_mfma(mine_g ? k[t][kk] : 0.f, q[t][kk], s);
-                float mx = -3.0e38f;
-                bool ok[4];
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
-                    mx = ok[reg] ? fmaxf(mx, s[reg]) : mx;
+                for (int t = 0; t < 4; ++t) {
+                    sT[2 * t] = dvs_mfma(g0 ? k[t][kk] : 0.f, q[t][kk], sT[2 * t]);
+                    sT[2 * t + 1] = dvs_mfma(g0 ? 0.f : k[t][kk], q[t][kk], sT[2 * t + 1]);
                 }
-                const float m = dvs_max_g(mx);
-                f4 pT;
+            bool ok[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
+            float m[8], den[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, sT[h][reg]) : mx;
+                m[h] = mx;
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 16));
+#pragma unroll
+            for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 32));
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
                 float sum = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    pT[reg] = ok[reg] ? __expf(s[reg] - m) : 0.f;
-                    sum += pT[reg];
+                    pT[h][reg] = ok[reg] ? __expf(sT[h][reg] - m[h]) : 0.f;
+                    sum += pT[h][reg];
                 }
-                const float den = dvs_sum_g(sum);
-                pT *= (1.0f / den);
-                const f4 pdT = drop_T(pT, kprob, h, D, L);
+                den[h] = sum;
+            }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) oN[t] = dvs_mfma(pdT[kk], mine_r ? v[t][kk] : 0.f, oN[t]);
-                f4 dpT = f4_zero();
+            for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 16);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dpT = dvs_mfma(mine_g ? vT[t][kk] : 0.f, dOT[t][kk], dpT);
-                dpT = drop_T(dpT, kprob, h, D, L);
+            for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 32);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                pT[h] *= (1.0f / den[h]);
+                lse[h] = m[h] + __logf(den[h]);
+            }
+        }
+        {
+            f4 mk[8], dpT[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                mk[h] = mask_T(kprob, h, D, L);
+                dpT[h] = f4_zero();
+            }
+            // O (N-layout, for dWo) = P' V ;  dP^T = V dO^T
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    oN[t] = dvs_mfma(pT[2 * t][kk] * mk[2 * t][kk], r0 ? v[t][kk] : 0.f, oN[t]);
+                    oN[t] = dvs_mfma(pT[2 * t + 1][kk] * mk[2 * t + 1][kk], r0 ? 0.f : v[t][kk], oN[t]);
+                    dpT[2 * t] = dvs_mfma(g0 ? vT[t][kk] : 0.f, dOT[t][kk], dpT[2 * t]);
+                    dpT[2 * t + 1] = dvs_mfma(g0 ? 0.f : vT[t][kk], dOT[t][kk], dpT[2 * t + 1]);
+                }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                dpT[h] *= mk[h];
                 float dl = 0.f;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dl += pT[reg] * dpT[reg];
-                const float delta = dvs_sum_g(dl);
-                f4 dsT;
+                for (int reg = 0; reg < 4; ++reg) dl += pT[h][reg] * dpT[h][reg];
+                delta[h] = dl;
+            }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dsT[reg] = pT[reg] * (dpT[reg] - delta);
+            for (int h = 0; h < 8; ++h) delta[h] += __shfl_xor(delta[h], 16);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dq[t] = dvs_mfma(mine_r ? kN[t][kk] : 0.f, dsT[kk], dq[t]);
-                // ---- S orientation ------------------------------------------------------------------------
-                f4 s2 = f4_zero();
+            for (int h = 0; h < 8; ++h) delta[h] += __shfl_xor(delta[h], 32);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) s2 = dvs_mfma(mine_g ? q[t][kk] : 0.f, k[t][kk], s2);
-                f4 p, dp = f4_zero();
+            for (int h = 0; h < 8; ++h)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dp = dvs_mfma(mine_g ? dOT[t][kk] : 0.f, vT[t][kk], dp);
-                dp = drop_S(dp, kprob, h, D, L);
-                f4 ds;
+                for (int reg = 0; reg < 4; ++reg) dsT[h][reg] = pT[h][reg] * (dpT[h][reg] - delta[h]);
+        }
+        // dq^T += K^T dS^T
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dq[t] = dvs_mfma(r0 ? kN[t][kk] : 0.f, dsT[2 * t][kk], dq[t]);
+                dq[t] = dvs_mfma(r0 ? 0.f : kN[t][kk], dsT[2 * t + 1][kk], dq[t]);
+            }
+        // row statistics (lse, delta) of query i move from lanes r = i to the S-orientation registers i = 4g+reg:
+        // through the wave's scratch tile, one b128 read per head and quantity
+        if (L.g == 0) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                scr[h * 32 + L.r] = lse[h];
+                scr[h * 32 + 16 + L.r] = delta[h];
+            }
+        }
+        dvs_wave_sync();
+        // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) ------------------------------------------------
+        {
+            f4 s2[8], dp[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) s2[h] = dp[h] = f4_zero();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s2[2 * t] = dvs_mfma(g0 ? q[t][kk] : 0.f, k[t][kk], s2[2 * t]);
+                    s2[2 * t + 1] = dvs_mfma(g0 ? 0.f : q[t][kk], k[t][kk], s2[2 * t + 1]);
+                    dp[2 * t] = dvs_mfma(g0 ? dOT[t][kk] : 0.f, vT[t][kk], dp[2 * t]);
+                    dp[2 * t + 1] = dvs_mfma(g0 ? 0.f : dOT[t][kk], vT[t][kk], dp[2 * t + 1]);
+                }
+            unsigned al4[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
+            f4 ds[8], pd[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const f4 lse_i = *(const f4*)(scr + h * 32 + 4 * L.g);
+                const f4 del_i = *(const f4*)(scr + h * 32 + 16 + 4 * L.g);
+                const f4 mk = mask_S(kprob, h, D, L);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int src = 4 * L.g + reg;
-                    const float m_i = __shfl(m, src), den_i = __shfl(den, src), delta_i = __shfl(delta, src);
                     const bool oki = (al4[reg] >> L.r) & 1u;
-                    p[reg] = oki ? __expf(s2[reg] - m_i) / den_i : 0.f;
-                    ds[reg] = p[reg] * (dp[reg] - delta_i);
+                    const float p = oki ? __expf(s2[h][reg] - lse_i[reg]) : 0.f;
+                    ds[h][reg] = p * (dp[h][reg] * mk[reg] - del_i[reg]);
+                    pd[h][reg] = p * mk[reg];
                 }
-                const f4 pd = drop_S(p, kprob, h, D, L);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dk[t] = dvs_mfma(mine_r ? qN[t][kk] : 0.f, ds[kk], dk[t]);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dv[t] = dvs_mfma(mine_r ? dON[t][kk] : 0.f, pd[kk], dv[t]);
             }
+            dvs_wave_sync();
+            // dk^T += Q^T dS ;  dv^T += dO^T P'
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dk[t] = dvs_mfma(r0 ? qN[t][kk] : 0.f, ds[2 * t][kk], dk[t]);
+                    dk[t] = dvs_mfma(r0 ? 0.f : qN[t][kk], ds[2 * t + 1][kk], dk[t]);
+                    dv[t] = dvs_mfma(r0 ? dON[t][kk] : 0.f, pd[2 * t][kk], dv[t]);
+                    dv[t] = dvs_mfma(r0 ? 0.f : dON[t][kk], pd[2 * t + 1][kk], dv[t]);
+                }
         }
         dvs_outer_acc<4, 4>(dWo, dyN, oN);
 #pragma unroll

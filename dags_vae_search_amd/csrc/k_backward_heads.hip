@@ -233,17 +233,16 @@ void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
 // Handles up to two gradient sources per DAG (encoder-side and decoder-side embeddings: same weights, different
 // dropout sites).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int EMB_LDW2 = 36;
 __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gout2, int site2) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
-    float* W1 = (float*)smem;                        // [32][LD]
+    float* W1 = (float*)smem;                        // [32][LD], rows >= 2N zero
     float* W2 = W1 + 2 * DVS_MAXTOK * DVS_LD;        // [64][36]
     float* labw = W2 + 64 * EMB_LDW2;                // [32][16]
     float* labb = labw + 32 * 16;                    // [32]
     float* scr0 = labb + 32;                         // nwaves tiles
-    float* accW1_0 = scr0 + 4 * DVS_SCR;             // nwaves x [32][64]
-    float* accLab_0 = accW1_0 + 4 * 2048;            // nwaves x [32][16]
+    for (int i = threadIdx.x; i < 2 * DVS_MAXTOK * DVS_LD; i += blockDim.x) W1[i] = 0.f;
+    __syncthreads();
     dvs_stage_matrix(W1, DVS_LD, a.W1, 64, 2 * N, 64);
     dvs_stage_matrix(W2, EMB_LDW2, a.W2, 32, 64, 32);
     for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
@@ -251,55 +250,40 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
         labw[i] = c < C ? a.lab_w[f * C + c] : 0.f;
     }
     dvs_stage_vector(labb, a.lab_b, 32);
-    for (int i = threadIdx.x; i < 4 * 2048 + 4 * 512; i += blockDim.x) accW1_0[i] = 0.f;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     float* scr = scr0 + L.wave * DVS_SCR;
-    float* accW1 = accW1_0 + L.wave * 2048;
-    float* accLab = accLab_0 + L.wave * 512;
-    f4 dW2[4][2], dlabb[2];
+    f4 dW2[4][2], dlabb[2], dW1a[1][4], dW1b[1][4], dlab[2][1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dW2[i][0] = dW2[i][1] = f4_zero();
-    dlabb[0] = dlabb[1] = f4_zero();
+    for (int i = 0; i < 4; ++i) dW2[i][0] = dW2[i][1] = dW1a[0][i] = dW1b[0][i] = f4_zero();
+    dlabb[0] = dlabb[1] = dlab[0][0] = dlab[1][0] = f4_zero();
     for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
         const DvsRecord* rec = a.rec + dag;
         const bool valid = L.r < N;
         const int label = rec->label[L.r];
-        const int pos = rec->pos[L.r];
-        const unsigned parents = rec->parents[L.r];
         const uint32_t gdag = a.dims.dag_offset + dag;
-        // hidden of the positional encoder (post-relu, pre-dropout), as in the forward
-        f4 e1[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) e1[t] = *(const f4*)(W1 + pos * DVS_LD + 16 * t + 4 * L.g);
-        for (int j = 0; j < N; ++j) {
-            const int pj = rec->pos[j];
-            const float on = ((parents >> j) & 1u) ? 1.f : 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) e1[t] += *(const f4*)(W1 + (N + pj) * DVS_LD + 16 * t + 4 * L.g) * on;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) e1[t][kk] = valid ? fmaxf(e1[t][kk], 0.f) : 0.f;
+        const EmbSel sel = dvs_emb_selectors(rec, N, scr, L);
+        f4 e1[4];                                    // hidden (post-relu, pre-dropout), as in the forward
+        dvs_emb_hidden(e1, W1, N, sel, L);
         for (int src = 0; src < 2; ++src) {
             const float* gsrc = src == 0 ? a.gout : gout2;
             if (!gsrc) continue;
             const int site = src == 0 ? a.site : site2;
             f4 gx[4];
             dvs_load_grad(gx, gsrc, dag, N, L);
-            // label half
+            // label half: d(relu(labw[:, label] + b))
+            f4 dle[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int f = 16 * t + 4 * L.g + kk;
                     const float pre = labw[f * 16 + label] + labb[f];
-                    const float d = (valid && pre > 0.f) ? gx[t][kk] : 0.f;
-                    dlabb[t][kk] += d;
-                    if (valid) atomicAdd(&accLab[f * 16 + label], d);
+                    dle[t][kk] = (valid && pre > 0.f) ? gx[t][kk] : 0.f;
                 }
+            dlabb[0] += dle[0];
+            dlabb[1] += dle[1];
             // positional half
             f4 e1d[4];
 #pragma unroll
@@ -313,9 +297,10 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
                 de2[0] = tmp[0];
                 de2[1] = tmp[1];
             }
-            f4 e1dN[4], de2N[2];
+            f4 e1dN[4], de2N[2], dleN[2];
             dvs_t2n<4>(e1dN, e1d, scr, L);
             dvs_t2n<2>(de2N, de2, scr, L);
+            dvs_t2n<2>(dleN, dle, scr, L);
             dvs_outer_acc<4, 2>(dW2, e1dN, de2N);
             f4 de1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
             dvs_mat_T<4, 2>(de1, de2, W2, EMB_LDW2, 0, L);
@@ -324,44 +309,28 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) de1[t][kk] = e1[t][kk] > 0.f ? de1[t][kk] : 0.f;
-            if (valid) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) atomicAdd(&accW1[pos * 64 + 16 * t + 4 * L.g + kk], de1[t][kk]);
-            }
-            for (int j = 0; j < N; ++j) {
-                if (valid && ((parents >> j) & 1u)) {
-                    const int row = N + rec->pos[j];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) atomicAdd(&accW1[row * 64 + 16 * t + 4 * L.g + kk], de1[t][kk]);
-                }
-            }
+            f4 de1N[4];
+            dvs_t2n<4>(de1N, de1, scr, L);
+            // row scatters as selector products: dW1a[p][c] += Sel[p][i] de1[i][c], dW1b likewise with Par;
+            // d labw^T: dlab[f][c] += dle[i][f] [label_i == c]
+            f4 selA[1] = {sel.selA}, parA[1] = {sel.parA}, labA[1] = {sel.labA};
+            dvs_outer_acc<1, 4>(dW1a, selA, de1N);
+            dvs_outer_acc<1, 4>(dW1b, parA, de1N);
+            dvs_outer_acc<2, 1>(dlab, dleN, labA);
         }
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    for (int i = threadIdx.x; i < 2 * N * 64; i += blockDim.x) {
-        float s = 0.f;
-        for (int w = 0; w < L.nwaves; ++w) s += accW1_0[w * 2048 + i];
-        slab[a.oW1 + i] = s;
-    }
-    for (int i = threadIdx.x; i < 32 * C; i += blockDim.x) {
-        const int f = i / C, c = i - f * C;
-        float s = 0.f;
-        for (int w = 0; w < L.nwaves; ++w) s += accLab_0[w * 512 + f * 16 + c];
-        slab[a.olab_w + i] = s;
-    }
-    __syncthreads();
     float* buf = (float*)smem;
+    dvs_reduce_dw<1, 4>(buf, dW1a, slab + a.oW1, L, N, 64);
+    dvs_reduce_dw<1, 4>(buf, dW1b, slab + a.oW1 + (size_t)N * 64, L, N, 64);
+    dvs_reduce_dw<2, 1>(buf, dlab, slab + a.olab_w, L, 32, C, C);
     dvs_reduce_dw<4, 2>(buf, dW2, slab + a.oW2, L);
     dvs_reduce_vec<2>(buf, dlabb, slab + a.olab_b, L);
 }
 
 void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
-    const size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR + 4 * 2048 + 4 * 512) * 4;
+    const size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
     DVS_SET_LDS(k_embed_bwd, lds);
     DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);
 }
@@ -371,154 +340,192 @@ void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int
 // the KL term to (d mu, d logvar); then d enc_out^T = [fc1;fc2]^T [dmu;dlogvar]^T, stored frag order.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
+    __shared__ f4 part[4][2][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
-    const int ngroups = (B + 15) >> 4;
     const int ldw = N * 64;
     const float gkl = a.gcoef[1];
-    for (int grp = blockIdx.x * L.nwaves + L.wave; grp < ngroups; grp += gridDim.x * L.nwaves) {
-        const int dag = grp * 16 + L.r;
-        const bool dvalid = dag < B;
-        f4 dz[2] = {f4_zero(), f4_zero()};
-        for (int m = 0; m < 64; ++m) {
-            const int tok = 4 * (m & 3) + L.g;
-            const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-            const bool tv = tok < N;
-            const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
-            const float* wp = a.fc3_w + (size_t)((tv ? tok : 0) * 64 + fb) * 32 + L.r;
+    const int dag = blockIdx.x * 16 + L.r;
+    const bool dvalid = dag < B;
+    const int m0 = 16 * L.wave;
+    f4 dz[2] = {f4_zero(), f4_zero()};
+#pragma unroll 4
+    for (int mi = 0; mi < 16; ++mi) {
+        const int m = m0 + mi;
+        const int tok = 4 * (m & 3) + L.g;
+        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        const bool tv = tok < N;
+        const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
+        const float* wp = a.fc3_w + (size_t)((tv ? tok : 0) * 64 + fb) * 32 + L.r;
+        f4 wa[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f4 wa;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wa[kk] = tv ? wp[kk * 32 + 16 * t] : 0.f;
+            for (int kk = 0; kk < 4; ++kk) wa[t][kk] = tv ? wp[kk * 32 + 16 * t] : 0.f;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dz[t] = dvs_mfma(wa[kk], gb[kk], dz[t]);
-            }
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dz[t] = dvs_mfma(wa[t][kk], gb[kk], dz[t]);
+    }
+    part[L.wave][0][L.lane] = dz[0];
+    part[L.wave][1][L.lane] = dz[1];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        dz[t] = part[0][t][L.lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) dz[t] += part[w][t][L.lane];
+    }
+    // dz[t][reg] = d z[o = 16t + 4g + reg][dag r]
+    f4 dout[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const size_t o4 = (size_t)(dvalid ? dag : 0) * 32 + 16 * t + 4 * L.g;
+        const f4 mu = *(const f4*)(a.mu + o4), lv = *(const f4*)(a.logvar + o4), ev = *(const f4*)(a.epsv + o4);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float dzz = dvalid ? dz[t][reg] : 0.f;
+            float dmu = dzz + gkl * mu[reg];
+            float dlv = gkl * 0.5f * (__expf(lv[reg]) - 1.0f);
+            if (a.dims.training) dlv += dzz * ev[reg] * 0.5f * __expf(0.5f * lv[reg]);
+            dout[t][reg] = dvalid ? dmu : 0.f;
+            dout[t + 2][reg] = dvalid ? dlv : 0.f;
         }
-        // dz[t][reg] = d z[o = 16t + 4g + reg][dag r]
-        f4 dout[4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const size_t o4 = (size_t)(dvalid ? dag : 0) * 32 + 16 * t + 4 * L.g;
-            const f4 mu = *(const f4*)(a.mu + o4), lv = *(const f4*)(a.logvar + o4), ev = *(const f4*)(a.epsv + o4);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float dzz = dvalid ? dz[t][reg] : 0.f;
-                float dmu = dzz + gkl * mu[reg];
-                float dlv = gkl * 0.5f * (__expf(lv[reg]) - 1.0f);
-                if (a.dims.training) dlv += dzz * ev[reg] * 0.5f * __expf(0.5f * lv[reg]);
-                dout[t][reg] = dvalid ? dmu : 0.f;
-                dout[t + 2][reg] = dvalid ? dlv : 0.f;
-            }
-            if (dvalid) {
-                *(f4*)(a.gz + (size_t)dag * 64 + 16 * t + 4 * L.g) = dout[t];
-                *(f4*)(a.gz + (size_t)dag * 64 + 32 + 16 * t + 4 * L.g) = dout[t + 2];
-            }
+        if (dvalid && L.wave == 0) {
+            *(f4*)(a.gz + (size_t)dag * 64 + 16 * t + 4 * L.g) = dout[t];
+            *(f4*)(a.gz + (size_t)dag * 64 + 32 + 16 * t + 4 * L.g) = dout[t + 2];
         }
-        // d enc_out^T[k'][dag] = sum_o Wfc[o][col(k')] dout^T[o][dag]
-        for (int m = 0; m < 64; ++m) {
-            const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-            const int tokD = 4 * (m & 3) + L.g;
-            const int tokA = 4 * (m & 3) + (L.r >> 2);
-            const bool av = tokA < N;
-            const size_t colA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
-            f4 o = f4_zero();
+    }
+    // d enc_out^T[k'][dag] = sum_o Wfc[o][col(k')] dout^T[o][dag]
+#pragma unroll 2
+    for (int mi = 0; mi < 16; ++mi) {
+        const int m = m0 + mi;
+        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        const int tokD = 4 * (m & 3) + L.g;
+        const int tokA = 4 * (m & 3) + (L.r >> 2);
+        const bool av = tokA < N;
+        const size_t colA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
+        f4 wa[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* wp = (t < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (t & 1) + 4 * L.g) * ldw + colA;
+        for (int t = 0; t < 4; ++t) {
+            const float* wp = (t < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (t & 1) + 4 * L.g) * ldw + colA;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(av ? wp[(size_t)kk * ldw] : 0.f, dout[t][kk], o);
-            }
-            if (dvalid) *(f4*)(a.genc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
+            for (int kk = 0; kk < 4; ++kk) wa[t][kk] = av ? wp[(size_t)kk * ldw] : 0.f;
         }
+        f4 o0 = f4_zero(), o1 = f4_zero();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            o0 = dvs_mfma(wa[0][kk], dout[0][kk], o0);
+            o1 = dvs_mfma(wa[1][kk], dout[1][kk], o1);
+            o0 = dvs_mfma(wa[2][kk], dout[2][kk], o0);
+            o1 = dvs_mfma(wa[3][kk], dout[3][kk], o1);
+        }
+        if (dvalid) *(f4*)(a.genc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o0 + o1 : f4_zero();
     }
 }
 
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
-    DVS_LAUNCH(k_latent_bwd, dim3((ngroups + 3) / 4), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_latent_bwd, dim3(ngroups), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Latent block backward, part 2: weight gradients of fc1/fc2/fc3 — batch-contraction GEMMs.  Workgroup s owns the
-// DAG range of slab s and writes its partial products straight into its slab (each wave a disjoint set of output
-// tiles), so no cross-wave reduction is needed.
+// Latent block backward, part 2: weight gradients of fc1/fc2/fc3 — batch-contraction GEMMs over ALL DAGs.
 //   dWfc[o][col(k')] = sum_dag dout[dag][o] X[dag][k'] ;  dW3[row(k')][o] = sum_dag dmem[dag][k'] z[dag][o]
+// Workgroup (m, q): output column tile m (16 frag columns k') x quarter q of the batch; its 4 waves split the
+// quarter, meet in LDS (fixed order) and write one partial per quarter to fcpart[q][param offset]; k_reduce_slabs
+// adds the DVS_FC_PARTS partials.  Bias gradients ride along (column sums of the same operands).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
+    __shared__ f4 red[4][8][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
     const int ldw = N * 64;
-    const int per = (B + a.nslab - 1) / a.nslab;
-    const int d0 = blockIdx.x * per;
-    const int d1 = (d0 + per < B) ? d0 + per : B;
-    float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    // ---- biases (thread per element) ----------------------------------------------------------------------
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) {
-        float s = 0.f;
-        for (int d = d0; d < d1; ++d) s += a.gz[(size_t)d * 64 + i];
-        if (i < 32) slab[a.o_fc1_b + i] = s; else slab[a.o_fc2_b + i - 32] = s;
+    const int m = blockIdx.x & 63, q = blockIdx.x >> 6;
+    const int per_q = (B + DVS_FC_PARTS - 1) / DVS_FC_PARTS;
+    const int per_w = (per_q + 3) / 4;
+    const int d0 = q * per_q + L.wave * per_w;
+    int d1 = d0 + per_w;
+    if (d1 > (q + 1) * per_q) d1 = (q + 1) * per_q;
+    if (d1 > B) d1 = B;
+    f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};   // dWfc tiles (o tile t) x k' tile m
+    f4 acc3[2] = {f4_zero(), f4_zero()};                           // dW3 tile: rows k' tile m, cols o tile t
+    float bs3 = 0.f;                                               // d b3 partial: column k' = 16m + r
+    f4 bsfc = f4_zero();                                           // d bfc partial: o = 16t + r (only m == 0)
+    for (int c0 = d0; c0 < d1; c0 += 16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int d = c0 + 4 * ks + L.g;
+            const bool dv = d < d1;
+            const size_t dd = dv ? d : 0;
+            const float xb = dv ? a.xenc[dd * DVS_TILE + 16 * m + L.r] : 0.f;
+            const float gm = dv ? a.gmem[dd * DVS_TILE + 16 * m + L.r] : 0.f;
+            bs3 += gm;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float ga = dv ? a.gz[dd * 64 + 16 * t + L.r] : 0.f;
+                bsfc[t] += ga;
+                acc[t] = dvs_mfma(ga, xb, acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float zb = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
+                acc3[t] = dvs_mfma(gm, zb, acc3[t]);
+            }
+        }
     }
-    for (int i = threadIdx.x; i < N * 64; i += blockDim.x) {
-        const int tok = i >> 6, f = i & 63;
-        const int k = (f >> 4) * 256 + ((((f >> 2) & 3) * 16 + tok) << 2) + (f & 3);   // frag index of (tok, f)
-        float s = 0.f;
-        for (int d = d0; d < d1; ++d) s += a.gmem[(size_t)d * DVS_TILE + k];
-        slab[a.o_fc3_b + i] = s;
+    bs3 = dvs_sum_g(bs3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bsfc[t] = dvs_sum_g(bsfc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[L.wave][t][L.lane] = acc[t];
+    red[L.wave][4][L.lane] = acc3[0];
+    red[L.wave][5][L.lane] = acc3[1];
+    red[L.wave][6][L.lane] = bsfc;
+    red[L.wave][7][L.lane] = f4{bs3, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (L.wave != 0) return;
+    f4 tot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tot[i] = red[0][i][L.lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) tot[i] += red[w][i][L.lane];
     }
-    // ---- weights: each wave walks output column tiles m = wave, wave+4, ... ------------------------------------
-    for (int m = L.wave; m < 64; m += L.nwaves) {
-        f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};   // dWfc tiles (o tile t) x k' tile m
-        f4 acc3[2] = {f4_zero(), f4_zero()};                           // dW3 tile: rows k' tile m, cols o tile t
-        for (int c0 = d0; c0 < d1; c0 += 16) {
+    float* out = a.fcpart + (size_t)q * a.P;
+    // tot[t][reg] = dWfc[o = 16t + 4g + reg][k' = 16m + r]
+    {
+        const int tok = 4 * (m & 3) + (L.r >> 2);
+        const int f = 16 * (m >> 4) + 4 * ((m >> 2) & 3) + (L.r & 3);
+        if (tok < N) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int d = c0 + 4 * ks + L.g;
-                const bool dv = d < d1;
-                const size_t dd = dv ? d : d0;
-                const float xb = dv ? a.xenc[dd * DVS_TILE + 16 * m + L.r] : 0.f;
-                const float gm = dv ? a.gmem[dd * DVS_TILE + 16 * m + L.r] : 0.f;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float ga = dv ? a.gz[dd * 64 + 16 * t + L.r] : 0.f;
-                    acc[t] = dvs_mfma(ga, xb, acc[t]);
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int o = 16 * (t & 1) + 4 * L.g + reg;
+                    out[(t < 2 ? a.o_fc1_w : a.o_fc2_w) + (size_t)o * ldw + tok * 64 + f] = tot[t][reg];
                 }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float zb = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
-                    acc3[t] = dvs_mfma(gm, zb, acc3[t]);
-                }
-            }
+            if (L.g == 0) out[a.o_fc3_b + tok * 64 + f] = tot[7][0];
         }
-        // acc[t][reg] = dWfc[o = 16t + 4g + reg][k' = 16m + r]
-        {
-            const int tok = 4 * (m & 3) + (L.r >> 2);
-            const int f = 16 * (m >> 4) + 4 * ((m >> 2) & 3) + (L.r & 3);
-            if (tok < N) {
+    }
+    // tot[4+t][reg] = dW3[row(k' = 16m + 4g + reg)][o = 16t + r]
+    {
+        const int tok = 4 * (m & 3) + L.g;
+        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        if (tok < N) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int o = 16 * (t & 1) + 4 * L.g + reg;
-                        slab[(t < 2 ? a.o_fc1_w : a.o_fc2_w) + (size_t)o * ldw + tok * 64 + f] = acc[t][reg];
-                    }
-            }
+                for (int reg = 0; reg < 4; ++reg)
+                    out[a.o_fc3_w + (size_t)(tok * 64 + fb + reg) * 32 + 16 * t + L.r] = tot[4 + t][reg];
         }
-        // acc3[t][reg] = dW3[row(k' = 16m + 4g + reg)][o = 16t + r]
-        {
-            const int tok = 4 * (m & 3) + L.g;
-            const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-            if (tok < N) {
+    }
+    if (m == 0 && L.g == 0) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        slab[a.o_fc3_w + (size_t)(tok * 64 + fb + reg) * 32 + 16 * t + L.r] = acc3[t][reg];
-            }
-        }
+        for (int t = 0; t < 4; ++t) out[(t < 2 ? a.o_fc1_b : a.o_fc2_b) + 16 * (t & 1) + L.r] = tot[6][t];
     }
 }
 
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st) {
-    DVS_LAUNCH(k_fc_dw, dim3(a.nslab), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_fc_dw, dim3(64 * DVS_FC_PARTS), dim3(256), 0, st, a);
 }

@@ -63,46 +63,26 @@ void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
 //   e1[i] = relu(W1[pos_i] + sum_{j parent of i} W1[N + pos_j]);  e2 = drop(drop(e1) @ W2)
 //   le[i] = relu(lab_w[:, label_i] + lab_b);                      x0 = cat(le, e2)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int EMB_LDW2 = 36;
 struct EmbLds {
-    float *W1, *W2, *labw, *labb;
+    float *W1, *W2, *labw, *labb, *scr;
 };
-__device__ __forceinline__ EmbLds emb_lds(char* smem, int N, int C) {
+__device__ __forceinline__ EmbLds emb_lds(char* smem) {
     EmbLds l;
     l.W1 = (float*)smem;
     l.W2 = l.W1 + 2 * DVS_MAXTOK * DVS_LD;
     l.labw = l.W2 + 64 * EMB_LDW2;
     l.labb = l.labw + 32 * 16;
+    l.scr = l.labb + 32;
     return l;
 }
-static size_t emb_lds_floats() { return 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32; }
+static size_t emb_lds_floats(int nwaves) { return 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + (size_t)nwaves * 16; }
 
-// hidden of the positional encoder, T-layout [64 x tok], before dropout
-__device__ __forceinline__ void emb_hidden(f4 (&e1)[4], const EmbLds& l, const DvsRecord* rec, int N, const Lane& L) {
-    const bool valid = L.r < N;
-    const int pos = rec->pos[L.r];
-    const unsigned parents = rec->parents[L.r];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) e1[t] = *(const f4*)(l.W1 + pos * DVS_LD + 16 * t + 4 * L.g);
-    for (int j = 0; j < N; ++j) {
-        const int pj = rec->pos[j];
-        const float on = ((parents >> j) & 1u) ? 1.f : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f4 w = *(const f4*)(l.W1 + (N + pj) * DVS_LD + 16 * t + 4 * L.g);
-            e1[t] += w * on;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) e1[t][kk] = valid ? fmaxf(e1[t][kk], 0.f) : 0.f;
-}
-
-__global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
+__global__ __launch_bounds__(512) void k_embed_fwd(EmbedArgs a) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
-    const EmbLds l = emb_lds(smem, N, C);
+    const EmbLds l = emb_lds(smem);
+    for (int i = threadIdx.x; i < 2 * DVS_MAXTOK * DVS_LD; i += blockDim.x) l.W1[i] = 0.f;
+    __syncthreads();
     dvs_stage_matrix(l.W1, DVS_LD, a.W1, 64, 2 * N, 64);
     dvs_stage_matrix(l.W2, EMB_LDW2, a.W2, 32, 64, 32);
     for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
@@ -113,24 +93,27 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
+    float* scr = l.scr + L.wave * 16;
     for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
         const DvsRecord* rec = a.rec + dag;
         const bool valid = L.r < N;
+        const EmbSel sel = dvs_emb_selectors(rec, N, scr, L);
         f4 e1[4];
-        emb_hidden(e1, l, rec, N, L);
+        dvs_emb_hidden(e1, l.W1, N, sel, L);
         const uint32_t gdag = a.dims.dag_offset + dag;
         dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site, gdag), D, L);
         f4 x[4];
         // positional half: e2^T[32 x tok] = W2^T e1^T  (A = W2 column fragments)
         f4 e2[2] = {f4_zero(), f4_zero()};
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
+        for (int t = 0; t < 4; ++t) {
+            const f4 w0 = dvs_wcol(l.W2, EMB_LDW2, 0, t, L), w1 = dvs_wcol(l.W2, EMB_LDW2, 16, t, L);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f4 w = dvs_wcol(l.W2, EMB_LDW2, 16 * ot, t, L);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) e2[ot] = dvs_mfma(w[kk], e1[t][kk], e2[ot]);
+            for (int kk = 0; kk < 4; ++kk) {
+                e2[0] = dvs_mfma(w0[kk], e1[t][kk], e2[0]);
+                e2[1] = dvs_mfma(w1[kk], e1[t][kk], e2[1]);
             }
+        }
         {
             f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
             dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L);
@@ -152,9 +135,9 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a) {
 }
 
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = emb_lds_floats() * 4;
+    const size_t lds = emb_lds_floats(8) * 4;
     DVS_SET_LDS(k_embed_fwd, lds);
-    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,32 +190,53 @@ __device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], con
     for (int t = 0; t < 4; ++t) q[t] *= scale;
 }
 
-// One head, "transposed" orientation: returns p[reg] = softmax_j(S[i=r][j=4g+reg]) (before dropout);
-// m, den = row max / denominator of query i = r.
-__device__ __forceinline__ f4 attn_probs_T(const f4& qt, const f4& kt, int hs, unsigned allowed_r, float& m, float& den,
-                                           const Lane& L) {
-    f4 s = f4_zero();
-    const bool mine = (L.g >> 1) == hs;
+// Attention core, all 8 heads, "transposed" orientation (lane r = query i, register reg = key 4g+reg).
+// Phase-structured so that independent work is adjacent for the scheduler: 8 score chains, then 8 softmaxes, then
+// 4 output-tile chains.  p[h][reg] = softmax_j(S_h[i=r][j=4g+reg]) before dropout; m/den = row max / denominator.
+__device__ __forceinline__ void attn_scores_T(f4 (&s)[8], const f4 (&q)[4], const f4 (&k)[4], const Lane& L) {
+    const bool g0 = (L.g >> 1) == 0;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) s = dvs_mfma(mine ? kt[kk] : 0.f, qt[kk], s);
-    float mx = -3.0e38f;
+    for (int h = 0; h < 8; ++h) s[h] = f4_zero();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[2 * t] = dvs_mfma(g0 ? k[t][kk] : 0.f, q[t][kk], s[2 * t]);
+            s[2 * t + 1] = dvs_mfma(g0 ? 0.f : k[t][kk], q[t][kk], s[2 * t + 1]);
+        }
+}
+__device__ __forceinline__ void attn_softmax_T(f4 (&p)[8], float (&m)[8], float (&den)[8], const f4 (&s)[8],
+                                               unsigned allowed_r, const Lane& L) {
     bool ok[4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
-        mx = ok[reg] ? fmaxf(mx, s[reg]) : mx;
-    }
-    m = dvs_max_g(mx);
-    f4 e;
-    float sum = 0.f;
+    for (int reg = 0; reg < 4; ++reg) ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        e[reg] = ok[reg] ? __expf(s[reg] - m) : 0.f;
-        sum += e[reg];
+    for (int h = 0; h < 8; ++h) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, s[h][reg]) : mx;
+        m[h] = mx;
     }
-    den = dvs_sum_g(sum);
-    const float inv = 1.0f / den;
-    return e * inv;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 16));
+#pragma unroll
+    for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 32));
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        float sum = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            p[h][reg] = ok[reg] ? __expf(s[h][reg] - m[h]) : 0.f;
+            sum += p[h][reg];
+        }
+        den[h] = sum;
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 16);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 32);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) p[h] *= (1.0f / den[h]);
 }
 
 // dropout on the probabilities of head h in the transposed orientation: element ((h*16 + i)*16 + j)
@@ -247,7 +251,7 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
     DVS_DYN_LDS(smem);
     const AttnLds l = attn_lds(smem);
     attn_stage(l, a.in_w, a.in_b, a.out_w, a.out_b, a.ln);
@@ -270,20 +274,23 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
+        f4 s[8], p[8];
+        float m[8], den[8];
+        attn_scores_T(s, q, k, L);
+        attn_softmax_T(p, m, den, s, allowed_r, L);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) p[h] = attn_drop_T(p[h], kprob, h, D, L);
         f4 o[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            o[t] = f4_zero();
+        for (int t = 0; t < 4; ++t) o[t] = f4_zero();
+        const bool r0 = (L.r >> 3) == 0;
 #pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-                float m, den;
-                f4 p = attn_probs_T(q[t], k[t], hs, allowed_r, m, den, L);
-                p = attn_drop_T(p, kprob, 2 * t + hs, D, L);
-                const bool mine = (L.r >> 3) == hs;
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) o[t] = dvs_mfma(mine ? v[t][kk] : 0.f, p[kk], o[t]);
+            for (int t = 0; t < 4; ++t) {
+                o[t] = dvs_mfma(r0 ? v[t][kk] : 0.f, p[2 * t][kk], o[t]);
+                o[t] = dvs_mfma(r0 ? 0.f : v[t][kk], p[2 * t + 1][kk], o[t]);
             }
-        }
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attn_lds_floats() * 4;
     DVS_SET_LDS(k_attn_fwd, lds);
-    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -324,7 +331,7 @@ __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
 }
 static size_t ffn_lds_floats() { return 128 * DVS_LD + 6 * 64; }
 
-__global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
+__global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
     DVS_DYN_LDS(smem);
     const FfnLds l = ffn_lds(smem);
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffn_lds_floats() * 4;
     DVS_SET_LDS(k_ffn_fwd, lds);
-    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(512), lds, st, a);
 }
 
 // frag-order [B][1024] -> natural [B][16][64] (debug / tests)

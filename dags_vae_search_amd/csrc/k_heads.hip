@@ -15,86 +15,101 @@ __device__ __forceinline__ float dvs_normal(uint32_t key, uint32_t e) {
     return sqrtf(-2.0f * __logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
+// One workgroup (4 waves) per group of 16 DAGs: the contraction (fc1/fc2) and the output rows (fc3) are split over the
+// waves by 16-float chunk index m; the fc1/fc2 partial sums meet in LDS and are added in wave order.
 __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
+    __shared__ f4 part[4][4][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
-    const int ngroups = (B + 15) >> 4;
     const int ldw = N * 64;
-    for (int grp = blockIdx.x * L.nwaves + L.wave; grp < ngroups; grp += gridDim.x * L.nwaves) {
-        const int dag = grp * 16 + L.r;
-        const bool dvalid = dag < B;
-        f4 acc[4];
+    const int grp = blockIdx.x;
+    const int dag = grp * 16 + L.r;
+    const bool dvalid = dag < B;
+    f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+    const int m0 = 16 * L.wave;
+#pragma unroll 4
+    for (int mi = 0; mi < 16; ++mi) {
+        const int m = m0 + mi;
+        const int tok = 4 * (m & 3) + L.g;
+        const int f0 = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        const bool tv = tok < N;
+        const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
+        const int col = (tv ? tok : 0) * 64 + f0;
+        f4 wa[4];
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) acc[ot] = *(const f4*)((ot < 2 ? a.fc1_b + 16 * ot : a.fc2_b + 16 * (ot - 2)) + 4 * L.g);
-        for (int m = 0; m < 64; ++m) {
-            const int tok = 4 * (m & 3) + L.g;
-            const int f0 = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-            const bool tv = tok < N;
-            const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
-            const int col = (tv ? tok : 0) * 64 + f0;
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                const float* wp = (ot < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (ot & 1) + L.r) * ldw + col;
-                const f4 wa = tv ? *(const f4*)wp : f4_zero();
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc[ot] = dvs_mfma(wa[kk], xb[kk], acc[ot]);
-            }
+        for (int ot = 0; ot < 4; ++ot) {
+            const float* wp = (ot < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (ot & 1) + L.r) * ldw + col;
+            wa[ot] = tv ? *(const f4*)wp : f4_zero();
         }
-        // acc[ot][reg] = out[o = 16(ot&1) + 4g + reg][dag r]; ot 0,1 = mu, ot 2,3 = logvar
-        float kl = 0.f;
-        f4 z[2];
-        const uint32_t key = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, 100u, a.dims.dag_offset + dag);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) acc[ot] = dvs_mfma(wa[ot][kk], xb[kk], acc[ot]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) part[L.wave][ot][L.lane] = acc[ot];
+    __syncthreads();
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        acc[ot] = *(const f4*)((ot < 2 ? a.fc1_b + 16 * ot : a.fc2_b + 16 * (ot - 2)) + 4 * L.g);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[ot] += part[w][ot][L.lane];
+    }
+    // acc[ot][reg] = out[o = 16(ot&1) + 4g + reg][dag r]; ot 0,1 = mu, ot 2,3 = logvar
+    float kl = 0.f;
+    f4 z[2];
+    const uint32_t key = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, 100u, a.dims.dag_offset + dag);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f4 ev = f4_zero();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float mu = acc[t][reg], lv = acc[t + 2][reg];
+            const float elv = __expf(lv);
+            kl += -0.5f * (1.0f + lv - mu * mu - elv);
+            float zz = mu;
+            if (a.dims.training) {
+                const int o = 16 * t + 4 * L.g + reg;
+                const float e = a.eps_in ? (dvalid ? a.eps_in[(size_t)dag * 32 + o] : 0.f)
+                                         : dvs_normal(key, (uint32_t)o) * a.dims.eps_scale;
+                ev[reg] = e;
+                zz = mu + e * __expf(0.5f * lv);
+            }
+            z[t][reg] = zz;
+        }
+        if (dvalid && L.wave == 0) {
+            const size_t o4 = (size_t)dag * 32 + 16 * t + 4 * L.g;
+            *(f4*)(a.mu + o4) = acc[t];
+            *(f4*)(a.logvar + o4) = acc[t + 2];
+            *(f4*)(a.z + o4) = z[t];
+            *(f4*)(a.epsv + o4) = ev;
+        }
+    }
+    kl = dvs_sum_g(kl);
+    if (L.wave == 0 && L.g == 0 && dvalid && a.dag_loss) a.dag_loss[(size_t)dag * 2 + 1] = kl;
+    if (!a.mem) return;
+#pragma unroll 4
+    for (int mi = 0; mi < 16; ++mi) {
+        const int m = m0 + mi;
+        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        const int tokD = 4 * (m & 3) + L.g;            // token of this lane's 4 result rows
+        const int tokA = 4 * (m & 3) + (L.r >> 2);     // token of this lane's A row
+        const bool av = tokA < N;
+        const size_t rowA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
+        f4 o = tokD < N ? *(const f4*)(a.fc3_b + tokD * 64 + fb) : f4_zero();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f4 ev = f4_zero();
+            const f4 wa = av ? *(const f4*)(a.fc3_w + rowA * 32 + 16 * t + 4 * L.g) : f4_zero();
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float mu = acc[t][reg], lv = acc[t + 2][reg];
-                const float elv = __expf(lv);
-                kl += -0.5f * (1.0f + lv - mu * mu - elv);
-                float zz = mu;
-                if (a.dims.training) {
-                    const int o = 16 * t + 4 * L.g + reg;
-                    const float e = a.eps_in ? (dvalid ? a.eps_in[(size_t)dag * 32 + o] : 0.f)
-                                             : dvs_normal(key, (uint32_t)o) * a.dims.eps_scale;
-                    ev[reg] = e;
-                    zz = mu + e * __expf(0.5f * lv);
-                }
-                z[t][reg] = zz;
-            }
-            if (dvalid) {
-                const size_t o4 = (size_t)dag * 32 + 16 * t + 4 * L.g;
-                *(f4*)(a.mu + o4) = acc[t];
-                *(f4*)(a.logvar + o4) = acc[t + 2];
-                *(f4*)(a.z + o4) = z[t];
-                *(f4*)(a.epsv + o4) = ev;
-            }
+            for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(wa[kk], z[t][kk], o);
         }
-        kl = dvs_sum_g(kl);
-        if (L.g == 0 && dvalid && a.dag_loss) a.dag_loss[(size_t)dag * 2 + 1] = kl;
-        if (!a.mem) continue;
-        for (int m = 0; m < 64; ++m) {
-            const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-            const int tokD = 4 * (m & 3) + L.g;            // token of this lane's 4 result rows
-            const int tokA = 4 * (m & 3) + (L.r >> 2);     // token of this lane's A row
-            const bool av = tokA < N;
-            const size_t rowA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
-            f4 o = tokD < N ? *(const f4*)(a.fc3_b + tokD * 64 + fb) : f4_zero();
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f4 wa = av ? *(const f4*)(a.fc3_w + rowA * 32 + 16 * t + 4 * L.g) : f4_zero();
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(wa[kk], z[t][kk], o);
-            }
-            if (dvalid) *(f4*)(a.mem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
-        }
+        if (dvalid) *(f4*)(a.mem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
     }
 }
 
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
-    const int grid = (ngroups + 3) / 4;
-    DVS_LAUNCH(k_latent_fwd, dim3(grid), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_latent_fwd, dim3(ngroups), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -145,7 +160,7 @@ __device__ __forceinline__ void loss_stage(const LossLds& l, const LossArgs& a) 
     dvs_stage_vector(l.lb, a.ln.b, 64);
 }
 
-__global__ __launch_bounds__(256) void k_loss_fwd(LossArgs a) {
+__global__ __launch_bounds__(512) void k_loss_fwd(LossArgs a) {
     DVS_DYN_LDS(smem);
     const LossLds l = loss_lds(smem);
     loss_stage(l, a);
@@ -221,9 +236,9 @@ __global__ __launch_bounds__(256) void k_loss_fwd(LossArgs a) {
 }
 
 void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = dvs_loss_lds_floats(4, 1) * 4;
+    const size_t lds = dvs_loss_lds_floats(8, 1) * 4;
     DVS_SET_LDS(k_loss_fwd, lds);
-    DVS_LAUNCH(k_loss_fwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_loss_fwd, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

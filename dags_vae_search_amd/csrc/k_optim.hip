@@ -1,20 +1,33 @@
 // clip_grad_norm_ + Adam over the flat parameter buffer (experiments/03_synthetic_12/main.py:115-116).
 #include "dvs_backward.h"
 
-// Deterministic global L2 norm: one workgroup, fixed summation order.  scratch[0] = sum of squares,
-// scratch[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_).
-__global__ __launch_bounds__(1024) void k_sqnorm(const float* g, int64_t n, float max_norm, float* scratch) {
-    __shared__ float part[1024];
+// Deterministic global L2 norm in two fixed-order stages: 256 workgroups write partial sums of squares to
+// scratch[2..258), one workgroup adds them.  scratch[0] = sum of squares, scratch[1] = clip coefficient
+// min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_).
+constexpr int SQ_PARTS = 256;
+__global__ __launch_bounds__(256) void k_sqnorm_part(const float* g, int64_t n, float* scratch) {
+    __shared__ float part[256];
     float s = 0.f;
     const int64_t n4 = n >> 2;
-    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)SQ_PARTS * 256) {
         const f4 v = *(const f4*)(g + 4 * i);
         s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) s += g[i] * g[i];
+    if (blockIdx.x == 0)
+        for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[2 + blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(256) void k_sqnorm_final(float max_norm, float* scratch) {
+    __shared__ float part[256];
+    part[threadIdx.x] = scratch[2 + threadIdx.x];
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
         if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
         __syncthreads();
     }
@@ -47,7 +60,8 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
 
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
                           float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st) {
-    DVS_LAUNCH(k_sqnorm, dim3(1), dim3(1024), 0, st, (const float*)grads, n, max_norm, scratch);
+    DVS_LAUNCH(k_sqnorm_part, dim3(SQ_PARTS), dim3(256), 0, st, (const float*)grads, n, scratch);
+    DVS_LAUNCH(k_sqnorm_final, dim3(1), dim3(256), 0, st, max_norm, scratch);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
     DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,

@@ -47,7 +47,7 @@ class Adam(torch.optim.Optimizer):
         if self._exp_avg is None or self._exp_avg.device != flat.device:
             self._exp_avg = torch.zeros_like(flat)
             self._exp_avg_sq = torch.zeros_like(flat)
-            self._scratch = torch.zeros(2, dtype=torch.float32, device=flat.device)
+            self._scratch = torch.zeros(320, dtype=torch.float32, device=flat.device)   # DVS_CLIP_SCRATCH_FLOATS
         g = self.param_groups[0]
         self._steps += 1
         model._eng().clip_adam(flat, grads, self._exp_avg, self._exp_avg_sq, float(g["lr"]), float(g["betas"][0]),

@@ -29,6 +29,7 @@ extern "C" {
 #define DVS_VERSION 100
 #define DVS_NUM_PARAMS 108
 #define DVS_RECORD_BYTES 96
+#define DVS_CLIP_SCRATCH_FLOATS 320
 
 typedef struct dvs_shape {
     int32_t batch;        /* DAGs in this (rank-local) batch */
@@ -86,7 +87,8 @@ int dvs_encode(const dvs_shape* s, const void* records, const float* params, voi
 
 /* clip_grad_norm_(params, max_norm) + Adam.step (experiments/03_synthetic_12/main.py:115-116, lr 1e-4,
  * betas (0.9, 0.999), eps 1e-8, no weight decay) over flat buffers of n floats.  max_norm <= 0 disables
- * clipping.  scratch: device f32[2] ({sum of squares, clip coefficient}); `step` is the 1-based Adam step. */
+ * clipping.  scratch: device f32[DVS_CLIP_SCRATCH_FLOATS] ([0] = sum of squares, [1] = clip coefficient, rest =
+ * partial sums); `step` is the 1-based Adam step. */
 int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
                   void* stream);

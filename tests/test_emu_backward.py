@@ -79,7 +79,7 @@ def test_emu_train0_golden_and_adam_step():
     gn = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
     exp_avg = np.zeros_like(m.flat)
     exp_avg_sq = np.zeros_like(m.flat)
-    scratch = np.zeros(2, np.float32)
+    scratch = np.zeros(320, np.float32)
     p = m.flat.copy()
     rc = m.lib.dvs_clip_adam(m.P, ptr(p), ptr(flat), ptr(exp_avg), ptr(exp_avg_sq), 1e-4, 0.9, 0.999, 1e-8, 1, 1.0,
                              ptr(scratch), None)

@@ -110,48 +110,78 @@ __device__ __forceinline__ f4 dvs_wcol(const float* W, int ld, int col0, int t, 
 __device__ __forceinline__ f4 dvs_vecT(const float* v, int t, const Lane& L) { return *(const f4*)(v + 16 * t + 4 * L.g); }
 
 // ---- register-chained products ----------------------------------------------------------------------------
+// All three walk the contraction in steps of one 16-feature tile: the weight fragments of step s+1 are fetched from
+// LDS (double-buffered, 2 x OT float4) while the 4*OT MFMAs of step s issue; a scheduling barrier per step keeps the
+// compiler from hoisting every fragment of the fully unrolled loop to the top (which costs >400 VGPRs and spills).
+// Within a step the contraction index kk is outermost and the output tile innermost, so OT independent accumulator
+// chains are in flight and the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 never stalls its 32-cycle issue.
+#ifdef DVS_EMU
+#define DVS_SCHED_FENCE() ((void)0)
+#else
+#define DVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // y^T[OT] (T) += W[row0 + 16*OT rows][16*IT cols] * x^T[IT] (T)
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_mat_T(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
-    // contraction step (t,kk) outermost, output tile innermost: OT independent accumulator chains are in flight, so the
-    // 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue rate
+    f4 w[OT], wn[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, 0, L);
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-        f4 w[OT];
+        if (t + 1 < IT) {
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+            for (int ot = 0; ot < OT; ++ot) wn[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t + 1, L);
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(w[ot][kk], x[t][kk], y[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) w[ot] = wn[ot];
+        DVS_SCHED_FENCE();
     }
 }
 // y[OT] (N) += x (T regs used as A) * W^T : y[dt][reg] = Y[token 4g+reg][16dt + r]
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_mat_N(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
+    f4 w[OT], wn[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, 0, L);
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-        f4 w[OT];
+        if (t + 1 < IT) {
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t, L);
+            for (int ot = 0; ot < OT; ++ot) wn[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t + 1, L);
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(x[t][kk], w[ot][kk], y[ot]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) w[ot] = wn[ot];
+        DVS_SCHED_FENCE();
     }
 }
 // dx^T[IT] (T) += W^T * dy^T[OT] (T), W = [16*OT rows (row0..)][16*IT cols]
 template <int IT, int OT>
 __device__ __forceinline__ void dvs_mat_Tt(f4 (&dx)[IT], const f4 (&dy)[OT], const float* W, int ld, int row0, const Lane& L) {
+    f4 w[IT], wn[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) w[it] = dvs_wcol(W + row0 * ld, ld, 16 * it, 0, L);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
-        f4 w[IT];
+        if (ot + 1 < OT) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) w[it] = dvs_wcol(W + row0 * ld, ld, 16 * it, ot, L);
+            for (int it = 0; it < IT; ++it) wn[it] = dvs_wcol(W + row0 * ld, ld, 16 * it, ot + 1, L);
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int it = 0; it < IT; ++it) dx[it] = dvs_mfma(w[it][kk], dy[ot][kk], dx[it]);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) w[it] = wn[it];
+        DVS_SCHED_FENCE();
     }
 }
 // dW[ot][it] += dY(N)[ot]^T (x) X(N)[it] over this DAG's 16 tokens; D = dW[16ot + 4g + reg][16it + r]

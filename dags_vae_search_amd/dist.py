@@ -33,3 +33,12 @@ def shard_features(features: Dict, rank: int, world: int, num_heads: int = 8) ->
         else:
             out[k] = v[lo:hi]
     return out, lo
+
+
+def allreduce_gradients(flat_grads: torch.Tensor, losses: torch.Tensor, group=None):
+    """The step's ONE exchange: SUM all-reduce of the flat gradient and of the [total, recon, kld, flag] scalars
+    (RCCL over xGMI on GPUs, gloo in the CPU tests).  Clipping and Adam run AFTER it, replicated on every rank."""
+    import torch.distributed as dist
+    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
+    return flat_grads, losses

@@ -47,10 +47,8 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
             optimizer.attach(model)
         losses = model.loss_and_grad(batch)
         if group is not None:
-            import torch.distributed as dist
-            pg = None if group is True else group
-            dist.all_reduce(model.flat_grads, op=dist.ReduceOp.SUM, group=pg)       # SUM, then clip
-            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=pg)
+            from .dist import allreduce_gradients
+            allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
         optimizer.step(max_grad_norm=max_grad_norm)
         host = losses.tolist()                                                      # the step's only host sync
         if host[3] != 0.0:

@@ -96,57 +96,59 @@ void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, floa
 size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave);
 
 // ---- slab reduction helpers ---------------------------------------------------------------------------------------
-// Ordered sum over the workgroup's waves of register weight-gradient tiles dw[ot][it][reg] = dW[16ot+4g+reg][16it+r],
-// written as a dense [16*OT][16*IT] matrix to dst (global slab).  buf: LDS scratch of 256*OT*IT floats.
-// Must be called by ALL threads of the workgroup (contains barriers).
+// After its DAG loop a workgroup adds its waves' register accumulators and writes ONE partial per parameter to its
+// slab.  Two-phase, so that all waves work in parallel and only two barriers are paid per batch of tensors:
+//   stage:  every wave dumps its accumulators into its own LDS region          (no barrier)
+//   -- __syncthreads() --
+//   flush:  all threads add the nwaves regions in fixed wave order and store to the slab (coalesced)
+// Region sizes (floats): matrix nwaves*256*OT*IT, vector nwaves*16*NT.  Callers lay the regions out in the
+// workgroup's LDS (the weight images are dead by then) and put a barrier between flush and the next stage that
+// reuses the space.
 template <int OT, int IT>
-__device__ __forceinline__ void dvs_reduce_dw(float* buf, const f4 (&dw)[OT][IT], float* dst, const Lane& L,
-                                              int rows = 16 * OT, int ld_dst = 16 * IT, int cols_used = 16 * IT) {
+__device__ __forceinline__ void dvs_stage_dw(float* region, const f4 (&dw)[OT][IT], const Lane& L) {
     constexpr int COLS = 16 * IT;
-    for (int w = 0; w < L.nwaves; ++w) {
-        if (L.wave == w) {
+    float* mine = region + L.wave * (256 * OT * IT);
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
+        for (int it = 0; it < IT; ++it)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int idx = (16 * ot + 4 * L.g + reg) * COLS + 16 * it + L.r;
-                        buf[idx] = (w == 0 ? 0.f : buf[idx]) + dw[ot][it][reg];
-                    }
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
-        const int row = i / COLS, col = i - row * COLS;
-        if (col < cols_used) dst[(size_t)row * ld_dst + col] = buf[i];
-    }
-    __syncthreads();
+            for (int reg = 0; reg < 4; ++reg) mine[(16 * ot + 4 * L.g + reg) * COLS + 16 * it + L.r] = dw[ot][it][reg];
 }
-// Same for a per-feature vector kept as T-layout per-lane partial sums v[t][kk] (feature 16t+4g+kk, summed over
-// the tokens r this lane handled): reduce over r with shuffles, then over waves through LDS.  n = 16*NT floats.
+// dense [16*OT][16*IT] sum -> dst[row * ld_dst + col] for row < rows, col < cols_used
+template <int OT, int IT>
+__device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, const Lane& L, int rows = 16 * OT,
+                                             int ld_dst = 16 * IT, int cols_used = 16 * IT) {
+    constexpr int COLS = 16 * IT, SZ = 256 * OT * IT;
+    for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
+        float s = region[i];
+        for (int w = 1; w < L.nwaves; ++w) s += region[w * SZ + i];
+        const int row = i / COLS, col = i - row * COLS;
+        if (col < cols_used) dst[(size_t)row * ld_dst + col] = s;
+    }
+}
+// per-feature vector kept as T-layout per-lane partial sums v[t][kk] (feature 16t+4g+kk, summed over the tokens r
+// this lane handled): reduce over r with shuffles, park one copy per wave
 template <int NT>
-__device__ __forceinline__ void dvs_reduce_vec(float* buf, const f4 (&v)[NT], float* dst, const Lane& L, int n = 16 * NT) {
-    f4 s[NT];
+__device__ __forceinline__ void dvs_stage_vec(float* region, const f4 (&v)[NT], const Lane& L) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) s[t][kk] = dvs_sum_r(v[t][kk]);
-    for (int w = 0; w < L.nwaves; ++w) {
-        if (L.wave == w && L.r == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int idx = 16 * t + 4 * L.g + kk;
-                    buf[idx] = (w == 0 ? 0.f : buf[idx]) + s[t][kk];
-                }
+        for (int kk = 0; kk < 4; ++kk) {
+            const float s = dvs_sum_r(v[t][kk]);
+            if (L.r == 0) region[L.wave * (16 * NT) + 16 * t + 4 * L.g + kk] = s;
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = buf[i];
-    __syncthreads();
 }
+template <int NT>
+__device__ __forceinline__ void dvs_flush_vec(const float* region, float* dst, const Lane& L, int n = 16 * NT) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float s = region[i];
+        for (int w = 1; w < L.nwaves; ++w) s += region[w * (16 * NT) + i];
+        dst[i] = s;
+    }
+}
+constexpr int DVS_RED_MAT = 4 * 4096;     // floats of a staged 64x64 matrix for 4 waves
+constexpr int DVS_RED_VEC = 4 * 64;       // floats of a staged 64-vector for 4 waves
 
 // LayerNorm backward for token r (T-layout): given dx (gradient w.r.t. the LayerNorm output), xhat, rstd and gamma,
 // returns d(pre) in place and accumulates d gamma / d beta partials.

@@ -89,8 +89,7 @@ __device__ __forceinline__ void dvs_stage_matrix(float* dst, int ldl, const floa
     const int c4 = cols >> 2;
     for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
         const int row = i / c4, c = (i - row * c4) << 2;
-        const float* s = src + (size_t)row * ldg + c;
-        *(f4*)(dst + row * ldl + c) = f4{s[0], s[1], s[2], s[3]};
+        *(f4*)(dst + row * ldl + c) = *(const f4*)(src + (size_t)row * ldg + c);   // all sources are 16-byte aligned
     }
 }
 __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __restrict__ src, int n) {

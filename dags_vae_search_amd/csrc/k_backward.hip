@@ -107,24 +107,37 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_store_tile(a.gout, dag, dx, L);
     }
     __syncthreads();
-    float* buf = (float*)smem;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    dvs_reduce_dw<4, 4>(buf, dW1, slab + a.o_l1_w, L);
-    dvs_reduce_dw<4, 4>(buf, dW2, slab + a.o_l2_w, L);
-    dvs_reduce_vec<4>(buf, db1, slab + a.o_l1_b, L);
-    dvs_reduce_vec<4>(buf, db2, slab + a.o_l2_b, L);
+    float* rW1 = (float*)smem;
+    float* rW2 = rW1 + DVS_RED_MAT;
+    float* rv = rW2 + DVS_RED_MAT;               // 6 vectors
+    dvs_stage_dw<4, 4>(rW1, dW1, L);
+    dvs_stage_dw<4, 4>(rW2, dW2, L);
+    dvs_stage_vec<4>(rv, db1, L);
+    dvs_stage_vec<4>(rv + DVS_RED_VEC, db2, L);
+    dvs_stage_vec<4>(rv + 2 * DVS_RED_VEC, dgam, L);
+    dvs_stage_vec<4>(rv + 3 * DVS_RED_VEC, dbet, L);
+    dvs_stage_vec<4>(rv + 4 * DVS_RED_VEC, dog, L);
+    dvs_stage_vec<4>(rv + 5 * DVS_RED_VEC, dob, L);
+    __syncthreads();
+    dvs_flush_dw<4, 4>(rW1, slab + a.o_l1_w, L);
+    dvs_flush_dw<4, 4>(rW2, slab + a.o_l2_w, L);
+    dvs_flush_vec<4>(rv, slab + a.o_l1_b, L);
+    dvs_flush_vec<4>(rv + DVS_RED_VEC, slab + a.o_l2_b, L);
     if (a.o_ln_g >= 0) {
-        dvs_reduce_vec<4>(buf, dgam, slab + a.o_ln_g, L);
-        dvs_reduce_vec<4>(buf, dbet, slab + a.o_ln_b, L);
+        dvs_flush_vec<4>(rv + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
+        dvs_flush_vec<4>(rv + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
     }
     if (a.o_own_g >= 0) {
-        dvs_reduce_vec<4>(buf, dog, slab + a.o_own_g, L);
-        dvs_reduce_vec<4>(buf, dob, slab + a.o_own_b, L);
+        dvs_flush_vec<4>(rv + 4 * DVS_RED_VEC, slab + a.o_own_g, L);
+        dvs_flush_vec<4>(rv + 5 * DVS_RED_VEC, slab + a.o_own_b, L);
     }
 }
 
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = ffnb_lds_floats(4) * 4;
+    size_t lds = ffnb_lds_floats(4) * 4;
+    const size_t red = (2 * DVS_RED_MAT + 6 * DVS_RED_VEC) * 4;
+    if (lds < red) lds = red;
     DVS_SET_LDS(k_ffn_bwd, lds);
     DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(256), lds, st, a);
 }
@@ -194,22 +207,35 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
         dvs_store_tile(a.gout, dag, dx, L);
     }
     __syncthreads();
-    float* buf = (float*)smem;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
+    float* rW = (float*)smem;                     // up to 2 matrices per pass
+    float* rv = rW + 2 * DVS_RED_MAT;             // NPROJ + 2 vectors
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) {
-        dvs_reduce_dw<4, 4>(buf, dW[p], slab + a.o_w + 4096 * p, L);
-        dvs_reduce_vec<4>(buf, db[p], slab + a.o_b + 64 * p, L);
-    }
-    if (a.o_ln_g >= 0) {
-        dvs_reduce_vec<4>(buf, dgam, slab + a.o_ln_g, L);
-        dvs_reduce_vec<4>(buf, dbet, slab + a.o_ln_b, L);
+    for (int p = 0; p < NPROJ; ++p) dvs_stage_vec<4>(rv + p * DVS_RED_VEC, db[p], L);
+    dvs_stage_vec<4>(rv + NPROJ * DVS_RED_VEC, dgam, L);
+    dvs_stage_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, dbet, L);
+#pragma unroll
+    for (int p0 = 0; p0 < NPROJ; p0 += 2) {
+        if (p0 > 0) __syncthreads();
+        dvs_stage_dw<4, 4>(rW, dW[p0], L);
+        if (p0 + 1 < NPROJ) dvs_stage_dw<4, 4>(rW + DVS_RED_MAT, dW[p0 + 1 < NPROJ ? p0 + 1 : p0], L);
+        __syncthreads();
+        dvs_flush_dw<4, 4>(rW, slab + a.o_w + 4096 * p0, L);
+        if (p0 + 1 < NPROJ) dvs_flush_dw<4, 4>(rW + DVS_RED_MAT, slab + a.o_w + 4096 * (p0 + 1), L);
+        if (p0 == 0) {
+#pragma unroll
+            for (int p = 0; p < NPROJ; ++p) dvs_flush_vec<4>(rv + p * DVS_RED_VEC, slab + a.o_b + 64 * p, L);
+            if (a.o_ln_g >= 0) {
+                dvs_flush_vec<4>(rv + NPROJ * DVS_RED_VEC, slab + a.o_ln_g, L);
+                dvs_flush_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, slab + a.o_ln_b, L);
+            }
+        }
     }
 }
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
     const size_t lds = ((size_t)64 * nproj * DVS_LD + 128 + 4 * DVS_SCR) * 4;
-    const size_t lds_min = 4096 * 4 + 64;   // reduction buffer
+    const size_t lds_min = (2 * DVS_RED_MAT + 5 * DVS_RED_VEC) * 4;   // epilogue staging
     const size_t bytes = lds > lds_min ? lds : lds_min;
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);

@@ -271,10 +271,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
         dvs_store_tile(a.gv, dag, dv, L);
     }
     __syncthreads();
-    float* buf = (float*)smem;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    dvs_reduce_dw<4, 4>(buf, dWo, slab + a.o_out_w, L);
-    dvs_reduce_vec<4>(buf, dbo, slab + a.o_out_b, L);
+    float* rW = (float*)smem;
+    float* rv = rW + DVS_RED_MAT;
+    dvs_stage_dw<4, 4>(rW, dWo, L);
+    dvs_stage_vec<4>(rv, dbo, L);
+    __syncthreads();
+    dvs_flush_dw<4, 4>(rW, slab + a.o_out_w, L);
+    dvs_flush_vec<4>(rv, slab + a.o_out_b, L);
 }
 
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {

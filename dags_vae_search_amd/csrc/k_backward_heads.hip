@@ -197,32 +197,52 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         dvs_store_tile(a.gout, dag, dh, L);
     }
     __syncthreads();
-    float* buf = (float*)smem;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    dvs_reduce_dw<2, 4>(buf, dWn1, slab + a.o_node0_w, L);
-    dvs_reduce_dw<1, 2>(buf, dWn2, slab + a.o_node2_w, L, C, 32);
-    dvs_reduce_dw<4, 4>(buf, dWa, slab + a.o_edge0_w, L, 64, 128);
-    dvs_reduce_dw<4, 4>(buf, dWb, slab + a.o_edge0_w + 64, L, 64, 128);
-    dvs_reduce_vec<2>(buf, dbn1, slab + a.o_node0_b, L);
-    dvs_reduce_vec<1>(buf, dbn2, slab + a.o_node2_b, L, C);
-    dvs_reduce_vec<4>(buf, dbe1, slab + a.o_edge0_b, L);
-    // dw2 is already a per-(lane c-set) sum over pairs: lanes with different r hold partials of the same feature
-    dvs_reduce_vec<4>(buf, dw2, slab + a.o_edge2_w, L);
-    dvs_reduce_vec<4>(buf, dgam, slab + a.o_ln_g, L);
-    dvs_reduce_vec<4>(buf, dbet, slab + a.o_ln_b, L);
-    // db2: scalar, lanes g == 0 hold partials
     {
-        const float s = dvs_sum_wave(L.g == 0 ? db2 : 0.f);
-        for (int w = 0; w < L.nwaves; ++w) {
-            if (L.wave == w && L.lane == 0) buf[0] = (w == 0 ? 0.f : buf[0]) + s;
-            __syncthreads();
+        // pass 1: the two 64x64 edge matrices; pass 2: node matrices + all vectors
+        float* rA = (float*)smem;
+        float* rB = rA + DVS_RED_MAT;
+        dvs_stage_dw<4, 4>(rA, dWa, L);
+        dvs_stage_dw<4, 4>(rB, dWb, L);
+        __syncthreads();
+        dvs_flush_dw<4, 4>(rA, slab + a.o_edge0_w, L, 64, 128);
+        dvs_flush_dw<4, 4>(rB, slab + a.o_edge0_w + 64, L, 64, 128);
+        __syncthreads();
+        float* rN1 = (float*)smem;                      // 4 * 2048
+        float* rN2 = rN1 + 4 * 2048;                    // 4 * 512
+        float* rv = rN2 + 4 * 512;
+        dvs_stage_dw<2, 4>(rN1, dWn1, L);
+        dvs_stage_dw<1, 2>(rN2, dWn2, L);
+        dvs_stage_vec<2>(rv, dbn1, L);
+        dvs_stage_vec<1>(rv + 128, dbn2, L);
+        dvs_stage_vec<4>(rv + 192, dbe1, L);
+        dvs_stage_vec<4>(rv + 192 + DVS_RED_VEC, dw2, L);      // per-lane partials over pairs: summed over r like a bias
+        dvs_stage_vec<4>(rv + 192 + 2 * DVS_RED_VEC, dgam, L);
+        dvs_stage_vec<4>(rv + 192 + 3 * DVS_RED_VEC, dbet, L);
+        const float sb2 = dvs_sum_wave(L.g == 0 ? db2 : 0.f);
+        float* rb2 = rv + 192 + 4 * DVS_RED_VEC;
+        if (L.lane == 0) rb2[L.wave] = sb2;
+        __syncthreads();
+        dvs_flush_dw<2, 4>(rN1, slab + a.o_node0_w, L);
+        dvs_flush_dw<1, 2>(rN2, slab + a.o_node2_w, L, C, 32);
+        dvs_flush_vec<2>(rv, slab + a.o_node0_b, L);
+        dvs_flush_vec<1>(rv + 128, slab + a.o_node2_b, L, C);
+        dvs_flush_vec<4>(rv + 192, slab + a.o_edge0_b, L);
+        dvs_flush_vec<4>(rv + 192 + DVS_RED_VEC, slab + a.o_edge2_w, L);
+        dvs_flush_vec<4>(rv + 192 + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
+        dvs_flush_vec<4>(rv + 192 + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
+        if (threadIdx.x == 0) {
+            float s = rb2[0];
+            for (int w = 1; w < L.nwaves; ++w) s += rb2[w];
+            slab[a.o_edge2_b] = s;
         }
-        if (threadIdx.x == 0) slab[a.o_edge2_b] = buf[0];
     }
 }
 
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = dvs_loss_lds_floats(4, 3) * 4;
+    size_t lds = dvs_loss_lds_floats(4, 3) * 4;
+    const size_t red = (2 * DVS_RED_MAT) * 4;
+    if (lds < red) lds = red;
     DVS_SET_LDS(k_loss_bwd, lds);
     DVS_LAUNCH(k_loss_bwd, dim3(grid), dim3(256), lds, st, a);
 }
@@ -321,16 +341,28 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* buf = (float*)smem;
-    dvs_reduce_dw<1, 4>(buf, dW1a, slab + a.oW1, L, N, 64);
-    dvs_reduce_dw<1, 4>(buf, dW1b, slab + a.oW1 + (size_t)N * 64, L, N, 64);
-    dvs_reduce_dw<2, 1>(buf, dlab, slab + a.olab_w, L, 32, C, C);
-    dvs_reduce_dw<4, 2>(buf, dW2, slab + a.oW2, L);
-    dvs_reduce_vec<2>(buf, dlabb, slab + a.olab_b, L);
+    float* r1a = (float*)smem;                 // 4 * 1024
+    float* r1b = r1a + 4 * 1024;               // 4 * 1024
+    float* rlab = r1b + 4 * 1024;              // 4 * 512
+    float* rW2 = rlab + 4 * 512;               // 4 * 2048
+    float* rv = rW2 + 4 * 2048;                // 4 * 32
+    dvs_stage_dw<1, 4>(r1a, dW1a, L);
+    dvs_stage_dw<1, 4>(r1b, dW1b, L);
+    dvs_stage_dw<2, 1>(rlab, dlab, L);
+    dvs_stage_dw<4, 2>(rW2, dW2, L);
+    dvs_stage_vec<2>(rv, dlabb, L);
+    __syncthreads();
+    dvs_flush_dw<1, 4>(r1a, slab + a.oW1, L, N, 64);
+    dvs_flush_dw<1, 4>(r1b, slab + a.oW1 + (size_t)N * 64, L, N, 64);
+    dvs_flush_dw<2, 1>(rlab, slab + a.olab_w, L, 32, C, C);
+    dvs_flush_dw<4, 2>(rW2, slab + a.oW2, L);
+    dvs_flush_vec<2>(rv, slab + a.olab_b, L);
 }
 
 void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
-    const size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
+    size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
+    const size_t red = (4 * (1024 + 1024 + 512 + 2048) + 4 * 32) * 4;
+    if (lds < red) lds = red;
     DVS_SET_LDS(k_embed_bwd, lds);
     DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);
 }

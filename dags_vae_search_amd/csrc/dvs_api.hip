@@ -1,6 +1,7 @@
 // C ABI (include/dvs.h): parameter/workspace layout and the launch sequences of the PACE-VAE step.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dvs_kernels.h"
@@ -238,6 +239,8 @@ static DvsDims make_dims(const dvs_shape* s) {
     d.dag_offset = s->dag_offset;
     d.beta = s->beta;
     d.eps_scale = s->eps_scale;
+    const char* dbg = getenv("DVS_DEBUG_SKIP");
+    d.debug = dbg ? atoi(dbg) : 0;
     return d;
 }
 

@@ -120,6 +120,15 @@ template <int OT, int IT>
 __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, const Lane& L, int rows = 16 * OT,
                                              int ld_dst = 16 * IT, int cols_used = 16 * IT) {
     constexpr int COLS = 16 * IT, SZ = 256 * OT * IT;
+    if (cols_used == COLS && (ld_dst & 3) == 0) {       // 16-byte path (every 64-wide tensor)
+        for (int i = threadIdx.x * 4; i < rows * COLS; i += blockDim.x * 4) {
+            f4 s = *(const f4*)(region + i);
+            for (int w = 1; w < L.nwaves; ++w) s += *(const f4*)(region + w * SZ + i);
+            const int row = i / COLS, col = i - row * COLS;
+            *(f4*)(dst + (size_t)row * ld_dst + col) = s;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
         float s = region[i];
         for (int w = 1; w < L.nwaves; ++w) s += region[w * SZ + i];
@@ -128,16 +137,21 @@ __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, co
     }
 }
 // per-feature vector kept as T-layout per-lane partial sums v[t][kk] (feature 16t+4g+kk, summed over the tokens r
-// this lane handled): reduce over r with shuffles, park one copy per wave
+// this lane handled).  The sum over the 16 token lanes goes through the wave's scratch tile: the partials are written
+// as a [16 tokens][64 features] tile and lane f adds column f (16 conflict-free LDS reads) — 20 LDS operations instead
+// of 64 dependent cross-lane shuffles per vector.  One copy per wave is parked in `region`.
 template <int NT>
-__device__ __forceinline__ void dvs_stage_vec(float* region, const f4 (&v)[NT], const Lane& L) {
+__device__ __forceinline__ void dvs_stage_vec(float* region, const f4 (&v)[NT], float* scr, const Lane& L) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) *(f4*)(scr + L.r * DVS_LD + 16 * t + 4 * L.g) = v[t];
+    dvs_wave_sync();
+    if (L.lane < 16 * NT) {
+        float s = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float s = dvs_sum_r(v[t][kk]);
-            if (L.r == 0) region[L.wave * (16 * NT) + 16 * t + 4 * L.g + kk] = s;
-        }
+        for (int rr = 0; rr < 16; ++rr) s += scr[rr * DVS_LD + L.lane];
+        region[L.wave * (16 * NT) + L.lane] = s;
+    }
+    dvs_wave_sync();
 }
 template <int NT>
 __device__ __forceinline__ void dvs_flush_vec(const float* region, float* dst, const Lane& L, int n = 16 * NT) {

@@ -40,6 +40,7 @@ struct DvsDims {
     DvsDropH drop;
     uint32_t seed_lo, seed_hi, dag_offset;
     float beta, eps_scale;
+    int debug;                  // DVS_DEBUG_SKIP timing experiments (0 in production)
 };
 
 // Workspace layout (float offsets unless noted); every region is 256-byte aligned.

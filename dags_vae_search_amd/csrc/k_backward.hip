@@ -26,8 +26,10 @@ static size_t ffnb_lds_floats(int nwaves) { return 128 * DVS_LD + 6 * 64 + (size
 __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
+    if (!(a.dims.debug & 4)) {
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
     dvs_stage_matrix(l.W2, DVS_LD, a.l2_w, 64, 64, 64);
+    }
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dW1[i][j] = dW2[i][j] = f4_zero();
     }
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < ((a.dims.debug & 2) ? 0 : a.dims.B); dag += gridDim.x * L.nwaves) {
         f4 x[4], xhat[4];
         float rstd;
         dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
@@ -107,18 +109,20 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_store_tile(a.gout, dag, dx, L);
     }
     __syncthreads();
+    if (a.dims.debug & 1) return;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     float* rW1 = (float*)smem;
     float* rW2 = rW1 + DVS_RED_MAT;
     float* rv = rW2 + DVS_RED_MAT;               // 6 vectors
+    float* es = rv + 6 * DVS_RED_VEC + L.wave * DVS_SCR;
     dvs_stage_dw<4, 4>(rW1, dW1, L);
     dvs_stage_dw<4, 4>(rW2, dW2, L);
-    dvs_stage_vec<4>(rv, db1, L);
-    dvs_stage_vec<4>(rv + DVS_RED_VEC, db2, L);
-    dvs_stage_vec<4>(rv + 2 * DVS_RED_VEC, dgam, L);
-    dvs_stage_vec<4>(rv + 3 * DVS_RED_VEC, dbet, L);
-    dvs_stage_vec<4>(rv + 4 * DVS_RED_VEC, dog, L);
-    dvs_stage_vec<4>(rv + 5 * DVS_RED_VEC, dob, L);
+    dvs_stage_vec<4>(rv, db1, es, L);
+    dvs_stage_vec<4>(rv + DVS_RED_VEC, db2, es, L);
+    dvs_stage_vec<4>(rv + 2 * DVS_RED_VEC, dgam, es, L);
+    dvs_stage_vec<4>(rv + 3 * DVS_RED_VEC, dbet, es, L);
+    dvs_stage_vec<4>(rv + 4 * DVS_RED_VEC, dog, es, L);
+    dvs_stage_vec<4>(rv + 5 * DVS_RED_VEC, dob, es, L);
     __syncthreads();
     dvs_flush_dw<4, 4>(rW1, slab + a.o_l1_w, L);
     dvs_flush_dw<4, 4>(rW2, slab + a.o_l2_w, L);
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
 
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
     size_t lds = ffnb_lds_floats(4) * 4;
-    const size_t red = (2 * DVS_RED_MAT + 6 * DVS_RED_VEC) * 4;
+    const size_t red = (2 * DVS_RED_MAT + 6 * DVS_RED_VEC + 4 * DVS_SCR) * 4;
     if (lds < red) lds = red;
     DVS_SET_LDS(k_ffn_bwd, lds);
     DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(256), lds, st, a);
@@ -210,10 +214,11 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     float* rW = (float*)smem;                     // up to 2 matrices per pass
     float* rv = rW + 2 * DVS_RED_MAT;             // NPROJ + 2 vectors
+    float* es = rv + 5 * DVS_RED_VEC + L.wave * DVS_SCR;
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) dvs_stage_vec<4>(rv + p * DVS_RED_VEC, db[p], L);
-    dvs_stage_vec<4>(rv + NPROJ * DVS_RED_VEC, dgam, L);
-    dvs_stage_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, dbet, L);
+    for (int p = 0; p < NPROJ; ++p) dvs_stage_vec<4>(rv + p * DVS_RED_VEC, db[p], es, L);
+    dvs_stage_vec<4>(rv + NPROJ * DVS_RED_VEC, dgam, es, L);
+    dvs_stage_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, dbet, es, L);
 #pragma unroll
     for (int p0 = 0; p0 < NPROJ; p0 += 2) {
         if (p0 > 0) __syncthreads();
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
     const size_t lds = ((size_t)64 * nproj * DVS_LD + 128 + 4 * DVS_SCR) * 4;
-    const size_t lds_min = (2 * DVS_RED_MAT + 5 * DVS_RED_VEC) * 4;   // epilogue staging
+    const size_t lds_min = (2 * DVS_RED_MAT + 5 * DVS_RED_VEC + 4 * DVS_SCR) * 4;   // epilogue staging
     const size_t bytes = lds > lds_min ? lds : lds_min;
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);

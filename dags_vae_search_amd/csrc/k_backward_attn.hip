@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
     float* rW = (float*)smem;
     float* rv = rW + DVS_RED_MAT;
     dvs_stage_dw<4, 4>(rW, dWo, L);
-    dvs_stage_vec<4>(rv, dbo, L);
+    dvs_stage_vec<4>(rv, dbo, rv + DVS_RED_VEC + L.wave * DVS_SCR, L);
     __syncthreads();
     dvs_flush_dw<4, 4>(rW, slab + a.o_out_w, L);
     dvs_flush_vec<4>(rv, slab + a.o_out_b, L);

@@ -213,12 +213,13 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         float* rv = rN2 + 4 * 512;
         dvs_stage_dw<2, 4>(rN1, dWn1, L);
         dvs_stage_dw<1, 2>(rN2, dWn2, L);
-        dvs_stage_vec<2>(rv, dbn1, L);
-        dvs_stage_vec<1>(rv + 128, dbn2, L);
-        dvs_stage_vec<4>(rv + 192, dbe1, L);
-        dvs_stage_vec<4>(rv + 192 + DVS_RED_VEC, dw2, L);      // per-lane partials over pairs: summed over r like a bias
-        dvs_stage_vec<4>(rv + 192 + 2 * DVS_RED_VEC, dgam, L);
-        dvs_stage_vec<4>(rv + 192 + 3 * DVS_RED_VEC, dbet, L);
+        float* es = rv + 192 + 4 * DVS_RED_VEC + 16 + L.wave * DVS_SCR;
+        dvs_stage_vec<2>(rv, dbn1, es, L);
+        dvs_stage_vec<1>(rv + 128, dbn2, es, L);
+        dvs_stage_vec<4>(rv + 192, dbe1, es, L);
+        dvs_stage_vec<4>(rv + 192 + DVS_RED_VEC, dw2, es, L);  // per-lane partials over pairs: summed over r like a bias
+        dvs_stage_vec<4>(rv + 192 + 2 * DVS_RED_VEC, dgam, es, L);
+        dvs_stage_vec<4>(rv + 192 + 3 * DVS_RED_VEC, dbet, es, L);
         const float sb2 = dvs_sum_wave(L.g == 0 ? db2 : 0.f);
         float* rb2 = rv + 192 + 4 * DVS_RED_VEC;
         if (L.lane == 0) rb2[L.wave] = sb2;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
     dvs_stage_dw<1, 4>(r1b, dW1b, L);
     dvs_stage_dw<2, 1>(rlab, dlab, L);
     dvs_stage_dw<4, 2>(rW2, dW2, L);
-    dvs_stage_vec<2>(rv, dlabb, L);
+    dvs_stage_vec<2>(rv, dlabb, rv + 4 * 32 + L.wave * DVS_SCR, L);
     __syncthreads();
     dvs_flush_dw<1, 4>(r1a, slab + a.oW1, L, N, 64);
     dvs_flush_dw<1, 4>(r1b, slab + a.oW1 + (size_t)N * 64, L, N, 64);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
 
 void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
     size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
-    const size_t red = (4 * (1024 + 1024 + 512 + 2048) + 4 * 32) * 4;
+    const size_t red = (4 * (1024 + 1024 + 512 + 2048) + 4 * 32 + 4 * DVS_SCR) * 4;
     if (lds < red) lds = red;
     DVS_SET_LDS(k_embed_bwd, lds);
     DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);

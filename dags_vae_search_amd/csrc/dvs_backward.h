@@ -33,6 +33,7 @@ struct ProjBwdArgs {             // backward of 1..3 stacked 64->64 projections 
     const float* gres;           // optional residual gradient added to dX before the LayerNorm backward
     float* gout;                 // result: d(pre of producer) / d(X)
     int accumulate_out;          // 1: gout += (decoder memory gradient over layers)
+    int slot_order;              // 1: the projections' output rows are in attention slot order (dvs_pi)
     float* slab;
     int64_t P;
     int64_t o_w, o_b, o_ln_g, o_ln_b;
@@ -118,14 +119,24 @@ __device__ __forceinline__ void dvs_stage_dw(float* region, const f4 (&dw)[OT][I
 // dense [16*OT][16*IT] sum -> dst[row * ld_dst + col] for row < rows, col < cols_used
 template <int OT, int IT>
 __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, const Lane& L, int rows = 16 * OT,
-                                             int ld_dst = 16 * IT, int cols_used = 16 * IT) {
+                                             int ld_dst = 16 * IT, int cols_used = 16 * IT, bool rperm = false,
+                                             bool cperm = false) {
     constexpr int COLS = 16 * IT, SZ = 256 * OT * IT;
+    if (cperm) {                                         // attention slot order -> parameter order (dvs_pi)
+        for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
+            float s = region[i];
+            for (int w = 1; w < L.nwaves; ++w) s += region[w * SZ + i];
+            const int row = i / COLS, col = i - row * COLS;
+            dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = s;
+        }
+        return;
+    }
     if (cols_used == COLS && (ld_dst & 3) == 0) {       // 16-byte path (every 64-wide tensor)
         for (int i = threadIdx.x * 4; i < rows * COLS; i += blockDim.x * 4) {
             f4 s = *(const f4*)(region + i);
             for (int w = 1; w < L.nwaves; ++w) s += *(const f4*)(region + w * SZ + i);
             const int row = i / COLS, col = i - row * COLS;
-            *(f4*)(dst + (size_t)row * ld_dst + col) = s;
+            *(f4*)(dst + (size_t)(rperm ? dvs_pi(row) : row) * ld_dst + col) = s;
         }
         return;
     }
@@ -154,11 +165,12 @@ __device__ __forceinline__ void dvs_stage_vec(float* region, const f4 (&v)[NT], 
     dvs_wave_sync();
 }
 template <int NT>
-__device__ __forceinline__ void dvs_flush_vec(const float* region, float* dst, const Lane& L, int n = 16 * NT) {
+__device__ __forceinline__ void dvs_flush_vec(const float* region, float* dst, const Lane& L, int n = 16 * NT,
+                                              bool perm = false) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float s = region[i];
         for (int w = 1; w < L.nwaves; ++w) s += region[w * (16 * NT) + i];
-        dst[i] = s;
+        dst[perm ? dvs_pi(i) : i] = s;
     }
 }
 constexpr int DVS_RED_MAT = 4 * 4096;     // floats of a staged 64x64 matrix for 4 waves

@@ -96,6 +96,27 @@ __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __rest
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// ---- head-aligned slot order inside the attention sublayers -------------------------------------------------------
+// A T-layout register (g, kk) of tile t normally holds feature 16t + 4g + kk, so one MFMA step (fixed kk, the 4 lane
+// groups g as contraction index) mixes features of BOTH heads of the tile (head = feature / 8).  q, k, v and the
+// attention output are internal to the sublayer, so their feature order is free: the in-projection ROWS and the
+// out-projection COLUMNS are staged into LDS permuted by the 4x4 transpose pi(4a + b) = 4b + a within every block of
+// 16.  Slot (g, kk) then holds feature 16t + 4kk + g: MFMA step kk contracts over 4 consecutive features of ONE head
+// (head 2t + (kk >> 1)), result rows reg <-> head 2t + (reg >> 1).  Scores need 2 unmasked MFMAs per head instead of
+// 4 half-masked ones, and the per-head outputs are merged by register selection.  pi is an involution.
+__device__ __forceinline__ int dvs_pi(int i) { return (i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3); }
+// LDS image dst[row][col] = src[rperm ? pi(row) : row][cperm ? pi(col) : col]
+__device__ __forceinline__ void dvs_stage_matrix_perm(float* dst, int ldl, const float* __restrict__ src, int ldg, int rows,
+                                                      int cols, bool rperm, bool cperm) {
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+        const int row = i / cols, col = i - row * cols;
+        dst[row * ldl + col] = src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)];
+    }
+}
+__device__ __forceinline__ void dvs_stage_vector_perm(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[dvs_pi(i)];
+}
+
 // row fragment: element kk = W[row0 + r][16t + 4g + kk]
 __device__ __forceinline__ f4 dvs_wrow(const float* W, int ld, int row0, int t, const Lane& L) {
     return *(const f4*)(W + (row0 + L.r) * ld + 16 * t + 4 * L.g);

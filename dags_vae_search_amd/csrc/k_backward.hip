@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
     float* lg = W + 64 * NPROJ * DVS_LD;
     float* lb = lg + 64;
     float* scr0 = lb + 64;
-    dvs_stage_matrix(W, DVS_LD, a.w, 64, 64 * NPROJ, 64);
+    if (a.slot_order) dvs_stage_matrix_perm(W, DVS_LD, a.w, 64, 64 * NPROJ, 64, true, false);
+    else dvs_stage_matrix(W, DVS_LD, a.w, 64, 64 * NPROJ, 64);
     if (a.ln.stats) {
         dvs_stage_vector(lg, a.ln.g, 64);
         dvs_stage_vector(lb, a.ln.b, 64);
@@ -225,11 +226,12 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
         dvs_stage_dw<4, 4>(rW, dW[p0], L);
         if (p0 + 1 < NPROJ) dvs_stage_dw<4, 4>(rW + DVS_RED_MAT, dW[p0 + 1 < NPROJ ? p0 + 1 : p0], L);
         __syncthreads();
-        dvs_flush_dw<4, 4>(rW, slab + a.o_w + 4096 * p0, L);
-        if (p0 + 1 < NPROJ) dvs_flush_dw<4, 4>(rW + DVS_RED_MAT, slab + a.o_w + 4096 * (p0 + 1), L);
+        const bool so = a.slot_order != 0;
+        dvs_flush_dw<4, 4>(rW, slab + a.o_w + 4096 * p0, L, 64, 64, 64, so, false);
+        if (p0 + 1 < NPROJ) dvs_flush_dw<4, 4>(rW + DVS_RED_MAT, slab + a.o_w + 4096 * (p0 + 1), L, 64, 64, 64, so, false);
         if (p0 == 0) {
 #pragma unroll
-            for (int p = 0; p < NPROJ; ++p) dvs_flush_vec<4>(rv + p * DVS_RED_VEC, slab + a.o_b + 64 * p, L);
+            for (int p = 0; p < NPROJ; ++p) dvs_flush_vec<4>(rv + p * DVS_RED_VEC, slab + a.o_b + 64 * p, L, 64, so);
             if (a.o_ln_g >= 0) {
                 dvs_flush_vec<4>(rv + NPROJ * DVS_RED_VEC, slab + a.o_ln_g, L);
                 dvs_flush_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, slab + a.o_ln_b, L);

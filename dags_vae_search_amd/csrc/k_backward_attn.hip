@@ -52,9 +52,9 @@ __device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, cons
 __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnBLds l = attnb_lds(smem);
-    dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
-    dvs_stage_matrix(l.Wout, DVS_LD, a.out_w, 64, 64, 64);
-    dvs_stage_vector(l.inb, a.in_b, 192);
+    dvs_stage_matrix_perm(l.Win, DVS_LD, a.in_w, 64, 192, 64, true, false);    // head-aligned slot order (dvs_device.h)
+    dvs_stage_matrix_perm(l.Wout, DVS_LD, a.out_w, 64, 64, 64, false, true);
+    dvs_stage_vector_perm(l.inb, a.in_b, 192);
     dvs_stage_vector(l.outb, a.out_b, 64);
     if (a.ln.stats) {
         dvs_stage_vector(l.lg, a.ln.g, 64);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
         dvs_t2n<4>(dON, dOT, scr, L);
 
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
-        const bool g0 = (L.g >> 1) == 0, r0 = (L.r >> 3) == 0;
+        const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
         f4 oN[4], dq[4], dk[4], dv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) oN[t] = dq[t] = dk[t] = dv[t] = f4_zero();
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
             for (int h = 0; h < 8; ++h) sT[h] = f4_zero();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    sT[2 * t] = dvs_mfma(g0 ? k[t][kk] : 0.f, q[t][kk], sT[2 * t]);
-                    sT[2 * t + 1] = dvs_mfma(g0 ? 0.f : k[t][kk], q[t][kk], sT[2 * t + 1]);
+                    sT[2 * t] = dvs_mfma(k[t][kk], q[t][kk], sT[2 * t]);
+                    sT[2 * t + 1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[2 * t + 1]);
                 }
             bool ok[4];
 #pragma unroll
@@ -175,15 +175,29 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
                 mk[h] = mask_T(kprob, h, D, L);
                 dpT[h] = f4_zero();
             }
-            // O (N-layout, for dWo) = P' V ;  dP^T = V dO^T
+            // O (N-layout, for dWo) = P' V (columns = slots: per-lane head select) ;  dP^T = V dO^T
+            {
+                f4 oa[4], ob[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int t = 0; t < 4; ++t) oa[t] = ob[t] = f4_zero();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        oa[t] = dvs_mfma(pT[2 * t][kk] * mk[2 * t][kk], v[t][kk], oa[t]);
+                        ob[t] = dvs_mfma(pT[2 * t + 1][kk] * mk[2 * t + 1][kk], v[t][kk], ob[t]);
+                    }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) oN[t][reg] = hsel ? ob[t][reg] : oa[t][reg];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    oN[t] = dvs_mfma(pT[2 * t][kk] * mk[2 * t][kk], r0 ? v[t][kk] : 0.f, oN[t]);
-                    oN[t] = dvs_mfma(pT[2 * t + 1][kk] * mk[2 * t + 1][kk], r0 ? 0.f : v[t][kk], oN[t]);
-                    dpT[2 * t] = dvs_mfma(g0 ? vT[t][kk] : 0.f, dOT[t][kk], dpT[2 * t]);
-                    dpT[2 * t + 1] = dvs_mfma(g0 ? 0.f : vT[t][kk], dOT[t][kk], dpT[2 * t + 1]);
+                    dpT[2 * t] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[2 * t]);
+                    dpT[2 * t + 1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[2 * t + 1]);
                 }
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
@@ -202,14 +216,21 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) dsT[h][reg] = pT[h][reg] * (dpT[h][reg] - delta[h]);
         }
-        // dq^T += K^T dS^T
+        // dq^T = K^T dS^T: all 16 slot rows per head, merged by register (rows reg 0,1 <-> head 2t)
+        {
+            f4 qa[4], qb[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int t = 0; t < 4; ++t) qa[t] = qb[t] = f4_zero();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dq[t] = dvs_mfma(r0 ? kN[t][kk] : 0.f, dsT[2 * t][kk], dq[t]);
-                dq[t] = dvs_mfma(r0 ? 0.f : kN[t][kk], dsT[2 * t + 1][kk], dq[t]);
-            }
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    qa[t] = dvs_mfma(kN[t][kk], dsT[2 * t][kk], qa[t]);
+                    qb[t] = dvs_mfma(kN[t][kk], dsT[2 * t + 1][kk], qb[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dq[t] = f4{qa[t][0], qa[t][1], qb[t][2], qb[t][3]};
+        }
         // row statistics (lse, delta) of query i move from lanes r = i to the S-orientation registers i = 4g+reg:
         // through the wave's scratch tile, one b128 read per head and quantity
         if (L.g == 0) {
@@ -226,13 +247,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
             for (int h = 0; h < 8; ++h) s2[h] = dp[h] = f4_zero();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    s2[2 * t] = dvs_mfma(g0 ? q[t][kk] : 0.f, k[t][kk], s2[2 * t]);
-                    s2[2 * t + 1] = dvs_mfma(g0 ? 0.f : q[t][kk], k[t][kk], s2[2 * t + 1]);
-                    dp[2 * t] = dvs_mfma(g0 ? dOT[t][kk] : 0.f, vT[t][kk], dp[2 * t]);
-                    dp[2 * t + 1] = dvs_mfma(g0 ? 0.f : dOT[t][kk], vT[t][kk], dp[2 * t + 1]);
+                    s2[2 * t] = dvs_mfma(q[t][kk], k[t][kk], s2[2 * t]);
+                    s2[2 * t + 1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[2 * t + 1]);
+                    dp[2 * t] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[2 * t]);
+                    dp[2 * t + 1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[2 * t + 1]);
                 }
             unsigned al4[4];
 #pragma unroll
@@ -252,16 +273,24 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
                 }
             }
             dvs_wave_sync();
-            // dk^T += Q^T dS ;  dv^T += dO^T P'
+            // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register)
+            f4 ka[4], kb[4], va[4], vb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ka[t] = kb[t] = va[t] = vb[t] = f4_zero();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    dk[t] = dvs_mfma(r0 ? qN[t][kk] : 0.f, ds[2 * t][kk], dk[t]);
-                    dk[t] = dvs_mfma(r0 ? 0.f : qN[t][kk], ds[2 * t + 1][kk], dk[t]);
-                    dv[t] = dvs_mfma(r0 ? dON[t][kk] : 0.f, pd[2 * t][kk], dv[t]);
-                    dv[t] = dvs_mfma(r0 ? 0.f : dON[t][kk], pd[2 * t + 1][kk], dv[t]);
+                    ka[t] = dvs_mfma(qN[t][kk], ds[2 * t][kk], ka[t]);
+                    kb[t] = dvs_mfma(qN[t][kk], ds[2 * t + 1][kk], kb[t]);
+                    va[t] = dvs_mfma(dON[t][kk], pd[2 * t][kk], va[t]);
+                    vb[t] = dvs_mfma(dON[t][kk], pd[2 * t + 1][kk], vb[t]);
                 }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dk[t] = f4{ka[t][0], ka[t][1], kb[t][2], kb[t][3]};
+                dv[t] = f4{va[t][0], va[t][1], vb[t][2], vb[t][3]};
+            }
         }
         dvs_outer_acc<4, 4>(dWo, dyN, oN);
 #pragma unroll
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
     dvs_stage_dw<4, 4>(rW, dWo, L);
     dvs_stage_vec<4>(rv, dbo, rv + DVS_RED_VEC + L.wave * DVS_SCR, L);
     __syncthreads();
-    dvs_flush_dw<4, 4>(rW, slab + a.o_out_w, L);
+    dvs_flush_dw<4, 4>(rW, slab + a.o_out_w, L, 64, 64, 64, false, true);   // columns back to parameter order
     dvs_flush_vec<4>(rv, slab + a.o_out_b, L);
 }
 

@@ -163,9 +163,9 @@ static size_t attn_lds_floats() { return 256 * DVS_LD + 192 + 64 + 128; }
 
 __device__ __forceinline__ void attn_stage(const AttnLds& l, const float* in_w, const float* in_b, const float* out_w,
                                            const float* out_b, const DvsLN& ln) {
-    dvs_stage_matrix(l.Win, DVS_LD, in_w, 64, 192, 64);
-    dvs_stage_matrix(l.Wout, DVS_LD, out_w, 64, 64, 64);
-    dvs_stage_vector(l.inb, in_b, 192);
+    dvs_stage_matrix_perm(l.Win, DVS_LD, in_w, 64, 192, 64, true, false);    // rows -> head-aligned slot order
+    dvs_stage_matrix_perm(l.Wout, DVS_LD, out_w, 64, 64, 64, false, true);   // columns likewise
+    dvs_stage_vector_perm(l.inb, in_b, 192);
     dvs_stage_vector(l.outb, out_b, 64);
     if (ln.stats) {
         dvs_stage_vector(l.lg, ln.g, 64);
@@ -194,15 +194,15 @@ __device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], con
 // Phase-structured so that independent work is adjacent for the scheduler: 8 score chains, then 8 softmaxes, then
 // 4 output-tile chains.  p[h][reg] = softmax_j(S_h[i=r][j=4g+reg]) before dropout; m/den = row max / denominator.
 __device__ __forceinline__ void attn_scores_T(f4 (&s)[8], const f4 (&q)[4], const f4 (&k)[4], const Lane& L) {
-    const bool g0 = (L.g >> 1) == 0;
 #pragma unroll
     for (int h = 0; h < 8; ++h) s[h] = f4_zero();
+    // slot order: step kk of tile t contracts 4 features of head 2t + (kk >> 1)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            s[2 * t] = dvs_mfma(g0 ? k[t][kk] : 0.f, q[t][kk], s[2 * t]);
-            s[2 * t + 1] = dvs_mfma(g0 ? 0.f : k[t][kk], q[t][kk], s[2 * t + 1]);
+            s[2 * t] = dvs_mfma(k[t][kk], q[t][kk], s[2 * t]);
+            s[2 * t + 1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], s[2 * t + 1]);
         }
 }
 __device__ __forceinline__ void attn_softmax_T(f4 (&p)[8], float (&m)[8], float (&den)[8], const f4 (&s)[8],
@@ -280,17 +280,22 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
         attn_softmax_T(p, m, den, s, allowed_r, L);
 #pragma unroll
         for (int h = 0; h < 8; ++h) p[h] = attn_drop_T(p[h], kprob, h, D, L);
+        // O^T = V^T P^T per head on all 16 feature rows of the tile; rows reg 0,1 belong to head 2t, rows 2,3 to 2t+1
         f4 o[4];
+        {
+            f4 oa[4], ob[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = f4_zero();
-        const bool r0 = (L.r >> 3) == 0;
+            for (int t = 0; t < 4; ++t) oa[t] = ob[t] = f4_zero();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                o[t] = dvs_mfma(r0 ? v[t][kk] : 0.f, p[2 * t][kk], o[t]);
-                o[t] = dvs_mfma(r0 ? 0.f : v[t][kk], p[2 * t + 1][kk], o[t]);
-            }
+                for (int t = 0; t < 4; ++t) {
+                    oa[t] = dvs_mfma(v[t][kk], p[2 * t][kk], oa[t]);
+                    ob[t] = dvs_mfma(v[t][kk], p[2 * t + 1][kk], ob[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = f4{oa[t][0], oa[t][1], ob[t][2], ob[t][3]};
+        }
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);

@@ -172,3 +172,48 @@ def test_full_size_properties_n12_b4096():
         loss_value, recon, kld = train_batch(f, model, opt)
         first = loss_value if first is None else first
     assert np.isfinite(loss_value) and loss_value < 0.97 * first
+
+
+def test_asia_b4096_elbo_matches_cpu_oracle():
+    """BASELINE config 2 (asia n=8, batch 4096 on one MI355X): ELBO vs the CPU path on the identical batch < 1e-4
+    relative, in eval mode and in train mode with the device's dropout masks (fp32 kernels; bf16 is not used)."""
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    ck = load_npz("asia_ckpt110.npz")
+    params = {k: torch.from_numpy(ck[k]) for k in ck.files}
+    cfg = po.PaceConfig(n=8, card=8)
+    graphs = synthetic_dags(8, 8, 4096, seed=21)
+    model = build_model(cfg, params)
+    f = model.prepare_features(graphs)
+    f_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()}
+    model.eval()
+    total, recon, kld = model.loss_direct(f)
+    with torch.no_grad():
+        t, r, k = po.loss_direct(params, cfg, f_cpu, training=False)
+    assert rel(total.item(), t) < 1e-4 and rel(recon.item(), r) < 1e-4 and rel(kld.item(), k) < 1e-4
+    model.train()
+    model.seed(3)
+    total, recon, kld = model.loss_direct(f)
+    masks = DeviceMasks((3 << 32) | 1, 0.15)
+    with torch.no_grad():
+        t, r, k = po.loss_direct(params, cfg, f_cpu, training=True, eps=torch.from_numpy(masks.eps(4096)), masks=masks)
+    assert rel(total.item(), t) < 1e-4 and rel(kld.item(), k) < 1e-4
+
+
+def test_sachs_shape_n11():
+    """BASELINE config 4's model shape (sachs: n=11, card=11, N=14 tokens) against the oracle, fwd + gradients."""
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    cfg = po.PaceConfig(n=11, card=11)
+    params = po.init_params(cfg, seed=11)
+    graphs = synthetic_dags(11, 11, 64, seed=4)
+    model = build_model(cfg, params).eval()
+    f = model.prepare_features(graphs)
+    total, recon, kld = model.loss_direct(f)
+    total.backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    t, r, k = po.loss_direct(P, cfg, {k2: (v.cpu() if torch.is_tensor(v) else v) for k2, v in f.items()})
+    t.backward()
+    assert rel(total.item(), t.detach()) < 1e-4
+    scale = max(float(p.grad.abs().max()) for p in P.values())
+    for name, p in model.named_parameters():
+        ref = P[name].grad.numpy()
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale) < 2e-3, name

@@ -11,7 +11,7 @@ constexpr int DVS_LATENT = 32;
 constexpr int DVS_FCH = 32;   // fc_hidden
 constexpr int DVS_EMB = 32;   // vertices_embedding_size
 constexpr int DVS_MAXTOK = 16;
-constexpr int DVS_FC_PARTS = 4;  // batch quarters of the fc1/fc2/fc3 weight-gradient GEMMs
+constexpr int DVS_FC_PARTS = 16; // batch parts of the fc1/fc2/fc3 weight-gradient GEMMs
 constexpr int DVS_NSLOTS = 17;   // saved activation slots: 0 enc-embed, 1..6 enc sublayers, 7 dec-embed, 8..16 dec sublayers
 
 struct DvsAttnP { int64_t in_w, in_b, out_w, out_b; };

@@ -465,65 +465,90 @@ void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 // Latent block backward, part 2: weight gradients of fc1/fc2/fc3 — batch-contraction GEMMs over ALL DAGs.
 //   dWfc[o][col(k')] = sum_dag dout[dag][o] X[dag][k'] ;  dW3[row(k')][o] = sum_dag dmem[dag][k'] z[dag][o]
-// Workgroup (m, q): output column tile m (16 frag columns k') x quarter q of the batch; its 4 waves split the
-// quarter, meet in LDS (fixed order) and write one partial per quarter to fcpart[q][param offset]; k_reduce_slabs
-// adds the DVS_FC_PARTS partials.  Bias gradients ride along (column sums of the same operands).
+// Workgroup (mg, q): 4 consecutive output column tiles (64 frag columns k') x batch part q (DVS_FC_PARTS parts); its
+// 4 waves split the part's DAGs, meet in LDS (fixed order) and write one partial per part to fcpart[q][param offset];
+// k_reduce_slabs adds the parts.  Per 4-DAG contraction step a lane issues 14 loads for 24 MFMAs; the [dag][64]
+// dout / [dag][32] z operands are shared by all column tiles (L2).  Bias gradients ride along as column sums.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int FC_MT = 4;     // column tiles per workgroup
 __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
-    __shared__ f4 red[4][8][64];
+    __shared__ f4 red[4][FC_MT * 6 + 2][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
     const int ldw = N * 64;
-    const int m = blockIdx.x & 63, q = blockIdx.x >> 6;
+    const int mg = blockIdx.x & 15, q = blockIdx.x >> 4;
     const int per_q = (B + DVS_FC_PARTS - 1) / DVS_FC_PARTS;
     const int per_w = (per_q + 3) / 4;
     const int d0 = q * per_q + L.wave * per_w;
     int d1 = d0 + per_w;
     if (d1 > (q + 1) * per_q) d1 = (q + 1) * per_q;
     if (d1 > B) d1 = B;
-    f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};   // dWfc tiles (o tile t) x k' tile m
-    f4 acc3[2] = {f4_zero(), f4_zero()};                           // dW3 tile: rows k' tile m, cols o tile t
-    float bs3 = 0.f;                                               // d b3 partial: column k' = 16m + r
-    f4 bsfc = f4_zero();                                           // d bfc partial: o = 16t + r (only m == 0)
+    f4 acc[FC_MT][4], acc3[FC_MT][2];
+    f4 bs3 = f4_zero();                                            // d b3 partials: column k' = 16(4mg+j) + r in [j]
+    f4 bsfc = f4_zero();                                           // d bfc partial: o = 16t + r (written by mg == 0)
+#pragma unroll
+    for (int j = 0; j < FC_MT; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = f4_zero();
+        acc3[j][0] = acc3[j][1] = f4_zero();
+    }
     for (int c0 = d0; c0 < d1; c0 += 16) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int d = c0 + 4 * ks + L.g;
             const bool dv = d < d1;
             const size_t dd = dv ? d : 0;
-            const float xb = dv ? a.xenc[dd * DVS_TILE + 16 * m + L.r] : 0.f;
-            const float gm = dv ? a.gmem[dd * DVS_TILE + 16 * m + L.r] : 0.f;
-            bs3 += gm;
+            float ga[4], zb[2], xb[FC_MT], gm[FC_MT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float ga = dv ? a.gz[dd * 64 + 16 * t + L.r] : 0.f;
-                bsfc[t] += ga;
-                acc[t] = dvs_mfma(ga, xb, acc[t]);
+            for (int t = 0; t < 4; ++t) ga[t] = dv ? a.gz[dd * 64 + 16 * t + L.r] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) zb[t] = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < FC_MT; ++j) {
+                xb[j] = dv ? a.xenc[dd * DVS_TILE + 16 * (FC_MT * mg + j) + L.r] : 0.f;
+                gm[j] = dv ? a.gmem[dd * DVS_TILE + 16 * (FC_MT * mg + j) + L.r] : 0.f;
+                bs3[j] += gm[j];
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float zb = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
-                acc3[t] = dvs_mfma(gm, zb, acc3[t]);
+            for (int t = 0; t < 4; ++t) bsfc[t] += ga[t];
+#pragma unroll
+            for (int j = 0; j < FC_MT; ++j) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[j][t] = dvs_mfma(ga[t], xb[j], acc[j][t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc3[j][t] = dvs_mfma(gm[j], zb[t], acc3[j][t]);
             }
         }
     }
-    bs3 = dvs_sum_g(bs3);
+#pragma unroll
+    for (int j = 0; j < FC_MT; ++j) bs3[j] = dvs_sum_g(bs3[j]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) bsfc[t] = dvs_sum_g(bsfc[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) red[L.wave][t][L.lane] = acc[t];
-    red[L.wave][4][L.lane] = acc3[0];
-    red[L.wave][5][L.lane] = acc3[1];
-    red[L.wave][6][L.lane] = bsfc;
-    red[L.wave][7][L.lane] = f4{bs3, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FC_MT; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[L.wave][6 * j + t][L.lane] = acc[j][t];
+        red[L.wave][6 * j + 4][L.lane] = acc3[j][0];
+        red[L.wave][6 * j + 5][L.lane] = acc3[j][1];
+    }
+    red[L.wave][6 * FC_MT][L.lane] = bsfc;
+    red[L.wave][6 * FC_MT + 1][L.lane] = bs3;
     __syncthreads();
-    if (L.wave != 0) return;
+    // wave w finalises column tile j = w
+    const int j = L.wave;
+    const int m = FC_MT * mg + j;
     f4 tot[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        tot[i] = red[0][i][L.lane];
+    for (int i = 0; i < 6; ++i) {
+        tot[i] = red[0][6 * j + i][L.lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) tot[i] += red[w][i][L.lane];
+        for (int w = 1; w < 4; ++w) tot[i] += red[w][6 * j + i][L.lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tot[6 + i] = red[0][6 * FC_MT + i][L.lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) tot[6 + i] += red[w][6 * FC_MT + i][L.lane];
     }
     float* out = a.fcpart + (size_t)q * a.P;
     // tot[t][reg] = dWfc[o = 16t + 4g + reg][k' = 16m + r]
@@ -538,7 +563,10 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
                     const int o = 16 * (t & 1) + 4 * L.g + reg;
                     out[(t < 2 ? a.o_fc1_w : a.o_fc2_w) + (size_t)o * ldw + tok * 64 + f] = tot[t][reg];
                 }
-            if (L.g == 0) out[a.o_fc3_b + tok * 64 + f] = tot[7][0];
+            if (L.g == 0) {
+                const float b3 = j == 0 ? tot[7][0] : j == 1 ? tot[7][1] : j == 2 ? tot[7][2] : tot[7][3];
+                out[a.o_fc3_b + tok * 64 + f] = b3;
+            }
         }
     }
     // tot[4+t][reg] = dW3[row(k' = 16m + 4g + reg)][o = 16t + r]
@@ -553,12 +581,12 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
                     out[a.o_fc3_w + (size_t)(tok * 64 + fb + reg) * 32 + 16 * t + L.r] = tot[4 + t][reg];
         }
     }
-    if (m == 0 && L.g == 0) {
+    if (mg == 0 && j == 0 && L.g == 0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) out[(t < 2 ? a.o_fc1_b : a.o_fc2_b) + 16 * (t & 1) + L.r] = tot[6][t];
     }
 }
 
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st) {
-    DVS_LAUNCH(k_fc_dw, dim3(64 * DVS_FC_PARTS), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_fc_dw, dim3(16 * DVS_FC_PARTS), dim3(256), 0, st, a);
 }

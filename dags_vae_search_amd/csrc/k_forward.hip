@@ -7,44 +7,67 @@
 // .to(device) hand-over; the features themselves come from prepare_features, pace.py:1345-1478).
 // One thread per (DAG, token slot).
 // ---------------------------------------------------------------------------------------------------------
+// A workgroup owns PACK_DAGS consecutive DAGs: their label / position / adjacency rows and their 8 per-head mask
+// copies are four CONTIGUOUS byte ranges of the batched feature tensors, streamed into LDS with 16-byte loads
+// (fully coalesced; the HBM-bound leg of the step: 4.5 KB per DAG at n=12), then one thread per (DAG, token) builds
+// its record fields from LDS.
+constexpr int PACK_DAGS = 16;
+__device__ __forceinline__ void pack_stream(float* dst, const float* __restrict__ src, size_t nfloats) {
+    const size_t n4 = nfloats >> 2;
+    for (size_t i = threadIdx.x; i < n4; i += blockDim.x) *(f4*)(dst + 4 * i) = *(const f4*)(src + 4 * i);
+    for (size_t i = 4 * n4 + threadIdx.x; i < nfloats; i += blockDim.x) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int dag = gid >> 4, i = gid & 15;
-    if (dag >= a.B) return;
+    DVS_DYN_LDS(smem);
     const int N = a.N, C = a.C;
+    const int dag0 = blockIdx.x * PACK_DAGS;
+    const int nd = (a.B - dag0 < PACK_DAGS) ? a.B - dag0 : PACK_DAGS;
+    float* s_lab = (float*)smem;                       // [PACK_DAGS][N][C]
+    float* s_pos = s_lab + PACK_DAGS * 16 * 16;        // [PACK_DAGS][N][N]
+    float* s_adj = s_pos + PACK_DAGS * 16 * 16;
+    float* s_msk = s_adj + PACK_DAGS * 16 * 16;        // [PACK_DAGS][8][N][N] bytes, streamed as floats
+    // DAG dag0's blocks start at multiples of 16 DAGs * {N*C, N*N} floats = multiples of 64 bytes: 16-byte loads are legal
+    pack_stream(s_lab, a.lab1h + (size_t)dag0 * N * C, (size_t)nd * N * C);
+    pack_stream(s_pos, a.pos1h + (size_t)dag0 * N * N, (size_t)nd * N * N);
+    pack_stream(s_adj, a.adj + (size_t)dag0 * N * N, (size_t)nd * N * N);
+    pack_stream(s_msk, (const float*)(a.tmask + (size_t)dag0 * 8 * N * N), (size_t)nd * 8 * N * N / 4);
+    __syncthreads();
+    const int d = threadIdx.x >> 4, i = threadIdx.x & 15;
+    if (d >= nd) return;
+    const uint8_t* msk = (const uint8_t*)s_msk;
     int bad = 0;
     int label = 0, pos = 0;
     unsigned parents = 0, allowed = 1u << i;
     if (i < N) {
-        const float* lr = a.lab1h + ((size_t)dag * N + i) * C;
+        const float* lr = s_lab + ((size_t)d * N + i) * C;
         int ones = 0;
         for (int c = 0; c < C; ++c) {
             const float v = lr[c];
             if (v == 1.0f) { label = c; ++ones; } else if (v != 0.0f) bad |= 1;
         }
         if (ones != 1) bad |= 1;
-        const float* pr = a.pos1h + ((size_t)dag * N + i) * N;
+        const float* pr = s_pos + ((size_t)d * N + i) * N;
         ones = 0;
         for (int c = 0; c < N; ++c) {
             const float v = pr[c];
             if (v == 1.0f) { pos = c; ++ones; } else if (v != 0.0f) bad |= 1;
         }
         if (ones != 1) bad |= 1;
-        const float* ad = a.adj + (size_t)dag * N * N;
+        const float* ad = s_adj + (size_t)d * N * N;
         for (int j = 0; j < N; ++j)
             if (ad[j * N + i] != 0.0f) parents |= 1u << j;
         allowed = 0;
-        const uint8_t* m0 = a.tmask + ((size_t)dag * 8 * N + i) * N;
+        const uint8_t* m0 = msk + ((size_t)d * 8 * N + i) * N;
         for (int j = 0; j < N; ++j)
             if (!m0[j]) allowed |= 1u << j;
         for (int h = 1; h < 8; ++h) {
-            const uint8_t* mh = a.tmask + (((size_t)dag * 8 + h) * N + i) * N;
+            const uint8_t* mh = msk + (((size_t)d * 8 + h) * N + i) * N;
             for (int j = 0; j < N; ++j)
                 if ((mh[j] != 0) != (m0[j] != 0)) bad |= 2;
         }
         if (!((allowed >> i) & 1u)) bad |= 4;
     }
-    DvsRecord* r = a.rec + dag;
+    DvsRecord* r = a.rec + dag0 + d;
     r->label[i] = (uint8_t)label;
     r->pos[i] = (uint8_t)pos;
     r->parents[i] = (uint16_t)parents;
@@ -53,8 +76,9 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 }
 
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
-    const int threads = a.B * 16;
-    DVS_LAUNCH(k_pack, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    const size_t lds = (size_t)PACK_DAGS * (3 * 256 * 4 + 8 * 256);
+    DVS_SET_LDS(k_pack, lds);
+    DVS_LAUNCH(k_pack, dim3((a.B + PACK_DAGS - 1) / PACK_DAGS), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -74,11 +74,14 @@ class PaceEngine:
             raise AssertionError(f"Expected [B,{self.n_tokens},{self.n_classes}] label features, got {tuple(lab.shape)}")
         if tuple(pos.shape) != (B, N, N) or tuple(adj.shape) != (B, N, N) or tuple(tm.shape) != (8 * B, N, N):
             raise AssertionError("feature tensors have inconsistent shapes")
-        lab = lab.contiguous().float()
-        pos = pos.contiguous().float()
-        adj = adj.contiguous().float()
-        tm = tm.contiguous()
-        tm = tm.view(torch.uint8) if tm.dtype == torch.bool else tm.to(torch.uint8)
+        def aligned(t):                     # dvs_pack_features streams with 16-byte loads
+            t = t.contiguous()
+            return t if t.data_ptr() % 16 == 0 else t.clone()
+        lab = aligned(lab.float())
+        pos = aligned(pos.float())
+        adj = aligned(adj.float())
+        tm = aligned(tm)
+        tm = tm.view(torch.uint8) if tm.dtype == torch.bool else aligned(tm.to(torch.uint8))
         self.workspace(B, lab.device)
         self._status.zero_()
         shape = self.shape(B)

@@ -116,181 +116,180 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
         const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
-        f4 oN[4], dq[4], dk[4], dv[4];
+        bool ok[4];
+        unsigned al4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) oN[t] = dq[t] = dk[t] = dv[t] = f4_zero();
-        // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) ------------------------------------------------
-        f4 pT[8], dsT[8];
-        float lse[8], delta[8];
-        {
-            f4 sT[8];
-#pragma unroll
-            for (int h = 0; h < 8; ++h) sT[h] = f4_zero();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    sT[2 * t] = dvs_mfma(k[t][kk], q[t][kk], sT[2 * t]);
-                    sT[2 * t + 1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[2 * t + 1]);
-                }
-            bool ok[4];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
-            float m[8], den[8];
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, sT[h][reg]) : mx;
-                m[h] = mx;
-            }
-#pragma unroll
-            for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 16));
-#pragma unroll
-            for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 32));
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                float sum = 0.f;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    pT[h][reg] = ok[reg] ? __expf(sT[h][reg] - m[h]) : 0.f;
-                    sum += pT[h][reg];
-                }
-                den[h] = sum;
-            }
-#pragma unroll
-            for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 16);
-#pragma unroll
-            for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 32);
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                pT[h] *= (1.0f / den[h]);
-                lse[h] = m[h] + __logf(den[h]);
-            }
+        for (int reg = 0; reg < 4; ++reg) {
+            ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
+            al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
         }
-        {
-            f4 mk[8], dpT[8];
+        f4 oN[4], dq[4], dk[4], dv[4];
+        // Heads are processed four at a time (tiles 2*half, 2*half+1): enough independent chains to cover the MFMA and
+        // cross-lane latencies, half the temporaries of an all-heads pass (the kernel sits at the 512-register limit).
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                mk[h] = mask_T(kprob, h, D, L);
-                dpT[h] = f4_zero();
-            }
-            // O (N-layout, for dWo) = P' V (columns = slots: per-lane head select) ;  dP^T = V dO^T
+        for (int half = 0; half < 2; ++half) {
+            // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) --------------------------------------------
+            f4 pT[4], dsT[4];
+            float lse[4], delta[4];
             {
-                f4 oa[4], ob[4];
+                f4 sT[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) oa[t] = ob[t] = f4_zero();
+                for (int u = 0; u < 4; ++u) sT[u] = f4_zero();
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        oa[t] = dvs_mfma(pT[2 * t][kk] * mk[2 * t][kk], v[t][kk], oa[t]);
-                        ob[t] = dvs_mfma(pT[2 * t + 1][kk] * mk[2 * t + 1][kk], v[t][kk], ob[t]);
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * half + tt;
+                        sT[2 * tt] = dvs_mfma(k[t][kk], q[t][kk], sT[2 * tt]);
+                        sT[2 * tt + 1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[2 * tt + 1]);
+                    }
+                float m[4], den[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, sT[u][reg]) : mx;
+                    m[u] = mx;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 16));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 32));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        pT[u][reg] = ok[reg] ? __expf(sT[u][reg] - m[u]) : 0.f;
+                        sum += pT[u][reg];
+                    }
+                    den[u] = sum;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) den[u] += __shfl_xor(den[u], 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) den[u] += __shfl_xor(den[u], 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pT[u] *= (1.0f / den[u]);
+                    lse[u] = m[u] + __logf(den[u]);
+                }
+            }
+            {
+                f4 mk[4], dpT[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mk[u] = mask_T(kprob, 4 * half + u, D, L);
+                    dpT[u] = f4_zero();
+                }
+                // O (N-layout, for dWo) = P' V: both heads of a tile on all 16 slot columns, per-lane head select
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * half + tt;
+                    f4 oa = f4_zero(), ob = f4_zero();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        oa = dvs_mfma(pT[2 * tt][kk] * mk[2 * tt][kk], v[t][kk], oa);
+                        ob = dvs_mfma(pT[2 * tt + 1][kk] * mk[2 * tt + 1][kk], v[t][kk], ob);
                     }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int reg = 0; reg < 4; ++reg) oN[t][reg] = hsel ? ob[reg] : oa[reg];
+                }
+                // dP^T = V dO^T
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) oN[t][reg] = hsel ? ob[t][reg] : oa[t][reg];
-            }
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * half + tt;
+                        dpT[2 * tt] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[2 * tt]);
+                        dpT[2 * tt + 1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[2 * tt + 1]);
+                    }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    dpT[2 * t] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[2 * t]);
-                    dpT[2 * t + 1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[2 * t + 1]);
+                for (int u = 0; u < 4; ++u) {
+                    dpT[u] *= mk[u];
+                    float dl = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dl += pT[u][reg] * dpT[u][reg];
+                    delta[u] = dl;
                 }
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                dpT[h] *= mk[h];
-                float dl = 0.f;
+                for (int u = 0; u < 4; ++u) delta[u] += __shfl_xor(delta[u], 16);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dl += pT[h][reg] * dpT[h][reg];
-                delta[h] = dl;
+                for (int u = 0; u < 4; ++u) delta[u] += __shfl_xor(delta[u], 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dsT[u][reg] = pT[u][reg] * (dpT[u][reg] - delta[u]);
             }
+            // dq^T = K^T dS^T: all 16 slot rows per head, merged by register (rows reg 0,1 <-> first head of the tile)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) delta[h] += __shfl_xor(delta[h], 16);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * half + tt;
+                f4 qa = f4_zero(), qb = f4_zero();
 #pragma unroll
-            for (int h = 0; h < 8; ++h) delta[h] += __shfl_xor(delta[h], 32);
-#pragma unroll
-            for (int h = 0; h < 8; ++h)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dsT[h][reg] = pT[h][reg] * (dpT[h][reg] - delta[h]);
-        }
-        // dq^T = K^T dS^T: all 16 slot rows per head, merged by register (rows reg 0,1 <-> head 2t)
-        {
-            f4 qa[4], qb[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) qa[t] = qb[t] = f4_zero();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    qa[t] = dvs_mfma(kN[t][kk], dsT[2 * t][kk], qa[t]);
-                    qb[t] = dvs_mfma(kN[t][kk], dsT[2 * t + 1][kk], qb[t]);
+                for (int kk = 0; kk < 4; ++kk) {
+                    qa = dvs_mfma(kN[t][kk], dsT[2 * tt][kk], qa);
+                    qb = dvs_mfma(kN[t][kk], dsT[2 * tt + 1][kk], qb);
                 }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dq[t] = f4{qa[t][0], qa[t][1], qb[t][2], qb[t][3]};
-        }
-        // row statistics (lse, delta) of query i move from lanes r = i to the S-orientation registers i = 4g+reg:
-        // through the wave's scratch tile, one b128 read per head and quantity
-        if (L.g == 0) {
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                scr[h * 32 + L.r] = lse[h];
-                scr[h * 32 + 16 + L.r] = delta[h];
+                dq[t] = f4{qa[0], qa[1], qb[2], qb[3]};
             }
-        }
-        dvs_wave_sync();
-        // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) ------------------------------------------------
-        {
-            f4 s2[8], dp[8];
+            // row statistics (lse, delta) of query i move from lanes r = i to the S-orientation registers i = 4g+reg
+            // through the wave's scratch tile: one b128 read per head and quantity
+            if (L.g == 0) {
 #pragma unroll
-            for (int h = 0; h < 8; ++h) s2[h] = dp[h] = f4_zero();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    s2[2 * t] = dvs_mfma(q[t][kk], k[t][kk], s2[2 * t]);
-                    s2[2 * t + 1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[2 * t + 1]);
-                    dp[2 * t] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[2 * t]);
-                    dp[2 * t + 1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[2 * t + 1]);
-                }
-            unsigned al4[4];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
-            f4 ds[8], pd[8];
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                const f4 lse_i = *(const f4*)(scr + h * 32 + 4 * L.g);
-                const f4 del_i = *(const f4*)(scr + h * 32 + 16 + 4 * L.g);
-                const f4 mk = mask_S(kprob, h, D, L);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const bool oki = (al4[reg] >> L.r) & 1u;
-                    const float p = oki ? __expf(s2[h][reg] - lse_i[reg]) : 0.f;
-                    ds[h][reg] = p * (dp[h][reg] * mk[reg] - del_i[reg]);
-                    pd[h][reg] = p * mk[reg];
+                for (int u = 0; u < 4; ++u) {
+                    scr[u * 32 + L.r] = lse[u];
+                    scr[u * 32 + 16 + L.r] = delta[u];
                 }
             }
             dvs_wave_sync();
-            // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register)
-            f4 ka[4], kb[4], va[4], vb[4];
+            // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) --------------------------------------------
+            {
+                f4 s2[4], dp[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ka[t] = kb[t] = va[t] = vb[t] = f4_zero();
+                for (int u = 0; u < 4; ++u) s2[u] = dp[u] = f4_zero();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    ka[t] = dvs_mfma(qN[t][kk], ds[2 * t][kk], ka[t]);
-                    kb[t] = dvs_mfma(qN[t][kk], ds[2 * t + 1][kk], kb[t]);
-                    va[t] = dvs_mfma(dON[t][kk], pd[2 * t][kk], va[t]);
-                    vb[t] = dvs_mfma(dON[t][kk], pd[2 * t + 1][kk], vb[t]);
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * half + tt;
+                        s2[2 * tt] = dvs_mfma(q[t][kk], k[t][kk], s2[2 * tt]);
+                        s2[2 * tt + 1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[2 * tt + 1]);
+                        dp[2 * tt] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[2 * tt]);
+                        dp[2 * tt + 1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[2 * tt + 1]);
+                    }
+                f4 ds[4], pd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f4 lse_i = *(const f4*)(scr + u * 32 + 4 * L.g);
+                    const f4 del_i = *(const f4*)(scr + u * 32 + 16 + 4 * L.g);
+                    const f4 mk = mask_S(kprob, 4 * half + u, D, L);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const bool oki = (al4[reg] >> L.r) & 1u;
+                        const float p = oki ? __expf(s2[u][reg] - lse_i[reg]) : 0.f;
+                        ds[u][reg] = p * (dp[u][reg] * mk[reg] - del_i[reg]);
+                        pd[u][reg] = p * mk[reg];
+                    }
                 }
+                dvs_wave_sync();
+                // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dk[t] = f4{ka[t][0], ka[t][1], kb[t][2], kb[t][3]};
-                dv[t] = f4{va[t][0], va[t][1], vb[t][2], vb[t][3]};
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * half + tt;
+                    f4 ka = f4_zero(), kb = f4_zero(), va = f4_zero(), vb = f4_zero();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        ka = dvs_mfma(qN[t][kk], ds[2 * tt][kk], ka);
+                        kb = dvs_mfma(qN[t][kk], ds[2 * tt + 1][kk], kb);
+                        va = dvs_mfma(dON[t][kk], pd[2 * tt][kk], va);
+                        vb = dvs_mfma(dON[t][kk], pd[2 * tt + 1][kk], vb);
+                    }
+                    dk[t] = f4{ka[0], ka[1], kb[2], kb[3]};
+                    dv[t] = f4{va[0], va[1], vb[2], vb[3]};
+                }
             }
+            DVS_SCHED_FENCE();
         }
         dvs_outer_acc<4, 4>(dWo, dyN, oN);
 #pragma unroll

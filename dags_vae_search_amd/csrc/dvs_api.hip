@@ -239,8 +239,7 @@ static DvsDims make_dims(const dvs_shape* s) {
     d.dag_offset = s->dag_offset;
     d.beta = s->beta;
     d.eps_scale = s->eps_scale;
-    const char* dbg = getenv("DVS_DEBUG_SKIP");
-    d.debug = dbg ? atoi(dbg) : 0;
+    d.debug = 0;
     return d;
 }
 

@@ -202,8 +202,10 @@ __device__ __forceinline__ void dvs_ln_bwd(f4 (&dx)[4], const f4 (&xhat)[4], flo
         for (int kk = 0; kk < 4; ++kk) dx[t][kk] = rstd * (dx[t][kk] - s1 - xhat[t][kk] * s2);
 }
 
-__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L) {
-    dvs_load_tile(g, base, dag, L);
+__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L,
+                                              const float* slot = nullptr) {
+    if (slot) dvs_slot_tile(g, slot, L);
+    else dvs_load_tile(g, base, dag, L);
     if (L.r >= N) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = f4_zero();

@@ -65,15 +65,15 @@ __device__ __forceinline__ f4 dvs_mfma(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Orders this wave's earlier LDS writes before its later LDS reads by other lanes (a wave's DS operations are
-// executed in issue order; the wait makes that explicit).  In the host emulator lanes are fibers, so this is a
-// real wave-wide rendezvous.
+// Orders this wave's earlier LDS accesses before its later ones as seen by its OTHER lanes (wave-private scratch
+// tiles).  The LDS executes one wave's DS instructions in issue order, so on the device this only has to stop the
+// compiler from reordering the accesses — no s_waitcnt: the data wait lands where the compiler needs the registers.
+// In the host emulator lanes are fibers, so there it is a real wave-wide rendezvous.
 __device__ __forceinline__ void dvs_wave_sync() {
 #ifdef DVS_EMU
     (void)emu::exchange(0, 0);
 #else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
@@ -254,6 +254,45 @@ __device__ __forceinline__ void dvs_store_tile(float* __restrict__ base, size_t 
     f4* p = (f4*)(base + dag * DVS_TILE) + L.lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) p[t * 64] = x[t];
+}
+
+// ---- LDS-DMA prefetch of the next DAG's tiles --------------------------------------------------------------------
+// Backward kernels run one wave per SIMD (their weight-gradient accumulators fill the register file), so nothing
+// hides the HBM latency of a DAG's input tiles.  Each wave therefore keeps a private LDS landing zone and, as soon as
+// it has copied the current DAG's tiles into registers, streams the NEXT DAG's tiles into it with
+// global_load_lds_dwordx4 (no registers, no wait): a frag-order tile is exactly the lane-linear 4 x 1 KiB image the
+// LDS-DMA writes.  At the top of the next iteration one s_waitcnt vmcnt(0) + 4 ds_read_b128 per tile replace the
+// exposed round trip to HBM.
+#ifdef DVS_EMU
+#define DVS_GLDS16(gptr, lptr, lane) memcpy((char*)(lptr) + (lane) * 16, (const void*)(gptr), 16)
+#define DVS_WAIT_VM() ((void)0)
+#define DVS_WAIT_LGKM() ((void)0)
+#else
+#define DVS_GLDS16(gptr, lptr, lane)                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#define DVS_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DVS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+// request tile `dag` of a frag-order buffer into this wave's LDS slot (4 x 1 KiB, lane-linear)
+__device__ __forceinline__ void dvs_prefetch_tile(float* slot, const float* __restrict__ base, size_t dag, const Lane& L) {
+    const float* g = base + dag * DVS_TILE + L.lane * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) DVS_GLDS16(g + t * 256, slot + t * 256, L.lane);
+}
+// all requested tiles have landed (call once per iteration, before dvs_slot_tile)
+__device__ __forceinline__ void dvs_prefetch_wait() {
+    DVS_WAIT_VM();
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void dvs_slot_tile(f4 (&x)[4], const float* slot, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = *(const f4*)(slot + t * 256 + L.lane * 4);
+}
+// the slot's contents are in registers: the slot may be overwritten by the next request
+__device__ __forceinline__ void dvs_slot_release() {
+    DVS_WAIT_LGKM();
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- reductions over the 64 features of a token (T-layout: 16 in-lane values x 4 lane groups g) --------------

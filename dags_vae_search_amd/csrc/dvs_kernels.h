@@ -133,31 +133,28 @@ __device__ __forceinline__ DvsDrop dvs_drop_of(const DvsDims& d) {
 // Rows of padding tokens (r >= N) are forced to zero.  xhat (optional) receives the normalised value.
 template <bool WANT_XHAT>
 __device__ __forceinline__ void dvs_load_x(f4 (&x)[4], f4 (&xhat)[4], float& rstd, const float* xin, const DvsLN& ln,
-                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L) {
-    dvs_load_tile(x, xin, dag, L);
-    const bool valid = L.r < N;
-    rstd = 1.f;
-    if (ln.stats) {
-        const float mean = ln.stats[dag * 32 + L.r];
-        rstd = ln.stats[dag * 32 + 16 + L.r];
+                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L,
+                                           const float* slot = nullptr) {
+    // whole-vector arithmetic only (element-wise updates of the loaded vectors inside the branch made hipcc route
+    // them through scratch memory).  slot != null: the tile was prefetched into this wave's LDS slot.
+    f4 raw[4];
+    if (slot) dvs_slot_tile(raw, slot, L);
+    else dvs_load_tile(raw, xin, dag, L);
+    const float vm = L.r < N ? 1.f : 0.f;
+    float mean = 0.f, rs = 1.f;
+    const bool has_ln = ln.stats != nullptr;
+    if (has_ln) {
+        mean = ln.stats[dag * 32 + L.r];
+        rs = ln.stats[dag * 32 + 16 + L.r];
+    }
+    rstd = rs;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f4 g = dvs_vecT(lg, t, L), b = dvs_vecT(lb, t, L);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float xh = valid ? (x[t][kk] - mean) * rstd : 0.f;
-                if (WANT_XHAT) xhat[t][kk] = xh;
-                x[t][kk] = valid ? xh * g[kk] + b[kk] : 0.f;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                x[t][kk] = valid ? x[t][kk] : 0.f;
-                if (WANT_XHAT) xhat[t][kk] = 0.f;
-            }
+    for (int t = 0; t < 4; ++t) {
+        const f4 g = has_ln ? dvs_vecT(lg, t, L) : f4_splat(1.f);
+        const f4 b = has_ln ? dvs_vecT(lb, t, L) : f4_zero();
+        const f4 xh = (raw[t] - mean) * (rs * vm);
+        if (WANT_XHAT) xhat[t] = has_ln ? xh : f4_zero();
+        x[t] = xh * g + b * vm;
     }
 }
 

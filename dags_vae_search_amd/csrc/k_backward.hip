@@ -21,15 +21,13 @@ __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     l.scr = l.ob + 64;
     return l;
 }
-static size_t ffnb_lds_floats(int nwaves) { return 128 * DVS_LD + 6 * 64 + (size_t)nwaves * DVS_SCR; }
+static size_t ffnb_lds_floats(int nwaves) { return 128 * DVS_LD + 6 * 64 + (size_t)nwaves * (DVS_SCR + 3 * DVS_TILE); }
 
 __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
-    if (!(a.dims.debug & 4)) {
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
     dvs_stage_matrix(l.W2, DVS_LD, a.l2_w, 64, 64, 64);
-    }
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {
@@ -45,6 +43,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
     float* scr = l.scr + L.wave * DVS_SCR;
+    float* pf = l.scr + L.nwaves * DVS_SCR + L.wave * 3 * DVS_TILE;    // LDS-DMA landing zone: x, d pre, own pre
     f4 dW1[4][4], dW2[4][4], db1[4], db2[4], dgam[4], dbet[4], dog[4], dob[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -52,18 +51,31 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dW1[i][j] = dW2[i][j] = f4_zero();
     }
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < ((a.dims.debug & 2) ? 0 : a.dims.B); dag += gridDim.x * L.nwaves) {
+    const int Bl = a.dims.B;
+    const int stride = gridDim.x * L.nwaves;
+    int dag = blockIdx.x * L.nwaves + L.wave;
+    if (dag < Bl) {
+        dvs_prefetch_tile(pf, a.xin, dag, L);
+        dvs_prefetch_tile(pf + DVS_TILE, a.gpre, dag, L);
+        if (a.own_pre) dvs_prefetch_tile(pf + 2 * DVS_TILE, a.own_pre, dag, L);
+    }
+    for (; dag < Bl; dag += stride) {
+        dvs_prefetch_wait();
         f4 x[4], xhat[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L, pf);
         f4 gp[4];
-        dvs_load_grad(gp, a.gpre, dag, N, L);
-        if (a.own_pre) {   // incoming gradient is w.r.t. LN_own(pre_own): pull back to d(pre_own)
-            f4 po[4], pxh[4];
-            float prstd;
-            dvs_load_x<true>(po, pxh, prstd, a.own_pre, a.own, l.og, l.ob, dag, N, L);
-            dvs_ln_bwd(gp, pxh, prstd, l.og, dog, dob, L);
+        dvs_load_grad(gp, a.gpre, dag, N, L, pf + DVS_TILE);
+        f4 po[4], pxh[4];
+        float prstd = 1.f;
+        if (a.own_pre) dvs_load_x<true>(po, pxh, prstd, a.own_pre, a.own, l.og, l.ob, dag, N, L, pf + 2 * DVS_TILE);
+        dvs_slot_release();
+        if (dag + stride < Bl) {
+            dvs_prefetch_tile(pf, a.xin, dag + stride, L);
+            dvs_prefetch_tile(pf + DVS_TILE, a.gpre, dag + stride, L);
+            if (a.own_pre) dvs_prefetch_tile(pf + 2 * DVS_TILE, a.own_pre, dag + stride, L);
         }
+        if (a.own_pre) dvs_ln_bwd(gp, pxh, prstd, l.og, dog, dob, L);   // d(LN_own(pre_own)) -> d(pre_own)
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t khid = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag);
         const uint32_t kpost = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag);
@@ -109,7 +121,6 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_store_tile(a.gout, dag, dx, L);
     }
     __syncthreads();
-    if (a.dims.debug & 1) return;
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     float* rW1 = (float*)smem;
     float* rW2 = rW1 + DVS_RED_MAT;
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
     const Lane L = dvs_lane();
     const int N = a.dims.N;
     float* scr = scr0 + L.wave * DVS_SCR;
+    float* pf = scr0 + L.nwaves * DVS_SCR + L.wave * (NPROJ + 2) * DVS_TILE;   // LDS-DMA landing zone: x, residual, dY_p
     f4 dW[NPROJ][4][4], db[NPROJ][4], dgam[4], dbet[4];
 #pragma unroll
     for (int p = 0; p < NPROJ; ++p)
@@ -179,28 +191,41 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
         }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dgam[i] = dbet[i] = f4_zero();
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    const int stride = gridDim.x * L.nwaves;
+    int dag = blockIdx.x * L.nwaves + L.wave;
+    auto request = [&](int d) {
+        dvs_prefetch_tile(pf, a.xin, d, L);
+        if (a.gres) dvs_prefetch_tile(pf + DVS_TILE, a.gres, d, L);
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) dvs_prefetch_tile(pf + (2 + p) * DVS_TILE, a.gy[p], d, L);
+    };
+    if (dag < a.dims.B) request(dag);
+    for (; dag < a.dims.B; dag += stride) {
+        dvs_prefetch_wait();
         f4 x[4], xhat[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dag, N, L);
-        f4 xN[4];
-        dvs_t2n<4>(xN, x, scr, L);
-        f4 dx[4];
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dag, N, L, pf);
+        f4 dy[NPROJ][4], dx[4];
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) dvs_load_grad(dy[p], a.gy[p], dag, N, L, pf + (2 + p) * DVS_TILE);
         if (a.gres) {
-            dvs_load_grad(dx, a.gres, dag, N, L);
+            dvs_load_grad(dx, a.gres, dag, N, L, pf + DVS_TILE);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
         }
+        dvs_slot_release();
+        if (dag + stride < a.dims.B) request(dag + stride);
+        f4 xN[4];
+        dvs_t2n<4>(xN, x, scr, L);
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
-            f4 dy[4], dyN[4];
-            dvs_load_grad(dy, a.gy[p], dag, N, L);
+            f4 dyN[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) db[p][t] += dy[t];
-            dvs_t2n<4>(dyN, dy, scr, L);
+            for (int t = 0; t < 4; ++t) db[p][t] += dy[p][t];
+            dvs_t2n<4>(dyN, dy[p], scr, L);
             dvs_outer_acc<4, 4>(dW[p], dyN, xN);
-            dvs_mat_Tt<4, 4>(dx, dy, W, DVS_LD, 64 * p, L);
+            dvs_mat_Tt<4, 4>(dx, dy[p], W, DVS_LD, 64 * p, L);
         }
         if (a.ln.stats) dvs_ln_bwd(dx, xhat, rstd, lg, dgam, dbet, L);
         if (a.accumulate_out) {
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
 }
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
-    const size_t lds = ((size_t)64 * nproj * DVS_LD + 128 + 4 * DVS_SCR) * 4;
+    const size_t lds = ((size_t)64 * nproj * DVS_LD + 128 + 4 * DVS_SCR + 4 * (size_t)(nproj + 2) * DVS_TILE) * 4;
     const size_t lds_min = (2 * DVS_RED_MAT + 5 * DVS_RED_VEC + 4 * DVS_SCR) * 4;   // epilogue staging
     const size_t bytes = lds > lds_min ? lds : lds_min;
     if (nproj == 3) {

@@ -23,7 +23,7 @@ __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
     l.scr = l.lb + 64;
     return l;
 }
-static size_t attnb_lds_floats(int nwaves) { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)nwaves * DVS_SCR; }
+static size_t attnb_lds_floats(int nwaves) { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)nwaves * (DVS_SCR + 3 * DVS_TILE); }
 
 // dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
 // reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
     float* scr = l.scr + L.wave * DVS_SCR;
+    float* pf = l.scr + L.nwaves * DVS_SCR + L.wave * 3 * DVS_TILE;   // LDS-DMA landing zone: x, kv, d pre
     const float scale = 0.35355339059327373f;
     f4 dWo[4][4], dbo[4];
 #pragma unroll
@@ -73,16 +74,29 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dWo[i][j] = f4_zero();
     }
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    const int stride = gridDim.x * L.nwaves;
+    int dag = blockIdx.x * L.nwaves + L.wave;
+    auto request = [&](int d) {
+        dvs_prefetch_tile(pf, a.xin, d, L);
+        if (a.kv) dvs_prefetch_tile(pf + DVS_TILE, a.kv, d, L);
+        dvs_prefetch_tile(pf + 2 * DVS_TILE, a.gpre, d, L);
+    };
+    if (dag < a.dims.B) request(dag);
+    for (; dag < a.dims.B; dag += stride) {
+        dvs_prefetch_wait();
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        f4 q[4], k[4], v[4];
+        f4 q[4], k[4], v[4], dy[4];
+        dvs_load_grad(dy, a.gpre, dag, N, L, pf + 2 * DVS_TILE);
+        const unsigned allowed_r = a.rec[dag].allowed[L.r];
         {
             f4 x[4], kv[4], dummy[4];
             float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L, pf);
+            if (a.kv) dvs_slot_tile(kv, pf + DVS_TILE, L);
+            dvs_slot_release();
+            if (dag + stride < a.dims.B) request(dag + stride);
             if (a.kv) {
-                dvs_load_tile(kv, a.kv, dag, L);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) kv[t] = x[t];
@@ -99,8 +113,6 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) q[t] *= scale;
         }
-        f4 dy[4];
-        dvs_load_grad(dy, a.gpre, dag, N, L);
         dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
 #pragma unroll
         for (int t = 0; t < 4; ++t) dbo[t] += dy[t];
@@ -114,7 +126,6 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
         dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
         dvs_t2n<4>(dON, dOT, scr, L);
 
-        const unsigned allowed_r = a.rec[dag].allowed[L.r];
         const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
         bool ok[4];
         unsigned al4[4];

@@ -79,6 +79,12 @@ __device__ __forceinline__ void dvs_wave_sync() {
 #endif
 }
 
+#ifdef DVS_EMU
+#define DVS_SCHED_FENCE() ((void)0)
+#else
+#define DVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 __device__ __forceinline__ f4 f4_zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f4 f4_splat(float v) { return f4{v, v, v, v}; }
 
@@ -135,11 +141,6 @@ __device__ __forceinline__ f4 dvs_vecT(const float* v, int t, const Lane& L) { r
 // compiler from hoisting every fragment of the fully unrolled loop to the top (which costs >400 VGPRs and spills).
 // Within a step the contraction index kk is outermost and the output tile innermost, so OT independent accumulator
 // chains are in flight and the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 never stalls its 32-cycle issue.
-#ifdef DVS_EMU
-#define DVS_SCHED_FENCE() ((void)0)
-#else
-#define DVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // y^T[OT] (T) += W[row0 + 16*OT rows][16*IT cols] * x^T[IT] (T)
 template <int OT, int IT>
@@ -227,6 +228,9 @@ __device__ __forceinline__ void dvs_t2n(f4 (&out)[NT], const f4 (&in)[NT], float
         out[t] = f4{p[0], p[DVS_LD], p[2 * DVS_LD], p[3 * DVS_LD]};
     }
     dvs_wave_sync();
+    // keep all 4*NT reads issued HERE, back to back: left alone, hipcc sinks each one next to the MFMA that consumes
+    // it and pays a full LDS round trip (s_waitcnt lgkmcnt(0)) every 8 MFMAs
+    DVS_SCHED_FENCE();
 }
 template <int NT>
 __device__ __forceinline__ void dvs_n2t(f4 (&out)[NT], const f4 (&in)[NT], float* scr, const Lane& L) {
@@ -242,6 +246,7 @@ __device__ __forceinline__ void dvs_n2t(f4 (&out)[NT], const f4 (&in)[NT], float
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = *(const f4*)(scr + L.r * DVS_LD + 16 * t + 4 * L.g);
     dvs_wave_sync();
+    DVS_SCHED_FENCE();
 }
 
 // ---- frag-order HBM tiles -----------------------------------------------------------------------------------

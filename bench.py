@@ -59,6 +59,21 @@ def bytes_per_dag(N: int, C: int, P: int, B_local: int) -> float:
     return N * C * 4 + 2 * N * N * 4 + 8 * N * N + 9.0 * P * 4 / B_local
 
 
+def pmc_traffic_bytes(kernel: str, batch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/r01_pmc_hbm.csv: FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), scaled to this batch; None if the
+    profile is absent or does not list the kernel.  Counters cannot be collected from inside the timed process."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_hbm.csv")
+    try:
+        for line in open(path):
+            parts = line.strip().split(",")
+            if len(parts) == 4 and parts[0].replace("void ", "") == kernel:
+                return float(parts[3]) * batch          # bytes per DAG x DAGs per launch
+    except OSError:
+        pass
+    return None
+
+
 def make_batch(batch: int, seed: int, device):
     from dags_vae_search_amd import prepare_features
     from dags_vae_search_amd.synthetic import synthetic_dags
@@ -116,15 +131,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="DAGs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the RCCL code path even with one rank (checks init / all-reduce plumbing on a 1-GPU box)")
     args = ap.parse_args()
+
+    # libraries (RCCL's version banner, ...) write to fd 1: keep stdout clean for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
@@ -192,7 +217,7 @@ def main():
         ach = flops.get(dom, 0.0) * args.batch / (kern[dom]["avg_us"] * 1e-6) / 1e12
         step_flops = 3 * 8.46e6 if (N_VERT, CARD) == (12, 12) else sum(flops.values())
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(dom, args.batch),
                     "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
                     "algorithmic_flops_per_dag": flops.get(dom, 0.0),
                     "whole_step": {"tflops": value / world * step_flops / 1e12,
@@ -216,7 +241,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graphs, feats)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,3 +7,4 @@ from .features import LabeledDag, LabeledGraph, collate_graph_batch, pace_collat
 from .pace import PaceVaeV3  # noqa: F401
 from .train import load_model_state, train_batch, train_model  # noqa: F401
 from . import optim  # noqa: F401
+from .records import CompactBatch, CompactDagDataset, encode_graphs  # noqa: F401

@@ -42,6 +42,8 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_workspace_bytes.argtypes = [P(DvsShape)]
     lib.dvs_pack_features.restype = c_int
     lib.dvs_pack_features.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_build_records.restype = c_int
+    lib.dvs_build_records.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_loss_forward.restype = c_int
     lib.dvs_loss_forward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]
@@ -62,7 +64,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_pack_features", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
+           "dvs_workspace_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
 
 

@@ -293,6 +293,22 @@ extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, 
     return 0;
 }
 
+extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const uint16_t* preds, void* records,
+                                 int32_t* status, void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!labels || !preds || !records || !status) return fail(10, "dvs_build_records: null pointer");
+    BuildArgs a;
+    a.B = s->batch;
+    a.N = s->n_tokens;
+    a.C = s->n_classes;
+    a.labels = labels;
+    a.preds = preds;
+    a.rec = (DvsRecord*)records;
+    a.status = status;
+    dvs_launch_build_records(a, (dvs_stream_t)stream);
+    return 0;
+}
+
 // slot numbering of saved activations
 static inline int slot_enc(int layer, int sub) { return 1 + 2 * layer + sub; }        // sub 0 attn, 1 ffn
 static inline int slot_dec(int layer, int sub) { return 8 + 3 * layer + sub; }        // sub 0 self, 1 cross, 2 ffn

@@ -94,6 +94,14 @@ struct FinalizeArgs {
     float* losses;               // [4]
 };
 
+struct BuildArgs {
+    int B, N, C;
+    const uint8_t* labels;       // [B][n]
+    const uint16_t* preds;       // [B][n]
+    DvsRecord* rec;
+    int* status;
+};
+void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st);
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st);
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st);

@@ -82,6 +82,100 @@ void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dvs_build_records: row codec -> records on the device, one thread per DAG.  Restates, for N <= 16
+// tokens held as 16-bit rows:
+//   PACE wrapping   (pace.py:1250-1288): v0 = start(2), v1 = input(0), v_{N-1} = output(1), user k -> k+2, label+3;
+//                   sources hang off v1, vertices without children feed v_{N-1}
+//   positions       (pace.py:1245-1248, 1286): FIFO Kahn order (zero in-degree vertices in id order, children relaxed in
+//                   ascending id) and the quirk positions[v] = order[v]
+//   ancestor mask   (pace.py:1307-1343 + .transpose at 1474): token i may attend j iff j reaches i or j == i
+// Per-thread arrays live in LDS ([entry][thread] so that a wave's accesses are conflict-free).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_records(BuildArgs a) {
+    __shared__ unsigned short s_child[16][256];
+    __shared__ unsigned short s_reach[16][256];
+    __shared__ unsigned char s_indeg[16][256];
+    __shared__ unsigned char s_order[16][256];
+    const int tid = threadIdx.x;
+    const int dag = blockIdx.x * 256 + tid;
+    if (dag >= a.B) return;
+    const int N = a.N, n = N - 3, out_id = N - 1;
+    int bad = 0;
+    for (int v = 0; v < 16; ++v) s_child[v][tid] = 0;
+    s_child[0][tid] = 1u << 1;
+    unsigned haspred = 0;
+    for (int v = 0; v < n; ++v) {
+        const unsigned p = a.preds[(size_t)dag * n + v];
+        if (p >> v) bad |= 8;                                   // an edge u -> v needs u < v
+        for (int u = 0; u < v; ++u)
+            if ((p >> u) & 1u) s_child[u + 2][tid] |= (unsigned short)(1u << (v + 2));
+        if (p & ((1u << v) - 1u)) haspred |= 1u << v;
+    }
+    for (int v = 0; v < n; ++v)
+        if (!((haspred >> v) & 1u)) s_child[1][tid] |= (unsigned short)(1u << (v + 2));
+    for (int v = 0; v < N - 1; ++v)
+        if (s_child[v][tid] == 0) s_child[v][tid] = (unsigned short)(1u << out_id);
+    // in-degrees and FIFO Kahn
+    for (int v = 0; v < 16; ++v) s_indeg[v][tid] = 0;
+    for (int u = 0; u < N; ++u) {
+        unsigned c = s_child[u][tid];
+        while (c) {
+            const int v = __ffs((int)c) - 1;
+            c &= c - 1;
+            s_indeg[v][tid]++;
+        }
+    }
+    int tail = 0;
+    for (int v = 0; v < N; ++v)
+        if (s_indeg[v][tid] == 0) s_order[tail++][tid] = (unsigned char)v;
+    for (int head = 0; head < tail && head < N; ++head) {
+        unsigned c = s_child[s_order[head][tid]][tid];
+        while (c) {
+            const int v = __ffs((int)c) - 1;
+            c &= c - 1;
+            if (--s_indeg[v][tid] == 0 && tail < 16) s_order[tail++][tid] = (unsigned char)v;
+        }
+    }
+    if (tail != N) bad |= 8;
+    // reach[a] = descendants-or-self of a (Warshall on bit rows)
+    for (int v = 0; v < N; ++v) s_reach[v][tid] = (unsigned short)(s_child[v][tid] | (1u << v));
+    for (int k = 0; k < N; ++k) {
+        const unsigned rk = s_reach[k][tid];
+        for (int v = 0; v < N; ++v)
+            if ((s_reach[v][tid] >> k) & 1u) s_reach[v][tid] |= (unsigned short)rk;
+    }
+    DvsRecord* r = a.rec + dag;
+    for (int i = 0; i < 16; ++i) {
+        int label = 0, pos = 0;
+        unsigned parents = 0, allowed = 1u << i;
+        if (i < N) {
+            if (i == 0) label = 2;
+            else if (i == 1) label = 0;
+            else if (i == out_id) label = 1;
+            else {
+                label = a.labels[(size_t)dag * n + (i - 2)] + 3;
+                if (label >= a.C) { bad |= 1; label = 0; }
+            }
+            pos = s_order[i][tid];
+            allowed = 0;
+            for (int j = 0; j < N; ++j) {
+                if ((s_child[j][tid] >> i) & 1u) parents |= 1u << j;
+                if ((s_reach[j][tid] >> i) & 1u) allowed |= 1u << j;
+            }
+        }
+        r->label[i] = (uint8_t)label;
+        r->pos[i] = (uint8_t)pos;
+        r->parents[i] = (uint16_t)parents;
+        r->allowed[i] = (uint16_t)allowed;
+    }
+    if (bad) atomicOr(a.status, bad);
+}
+
+void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st) {
+    DVS_LAUNCH(k_build_records, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Embedding (GnnPositionalEncoding.forward pace.py:201-221 + vertex_label_embed 1181-1184 + cat 1624-1630).
 // One-hot inputs make both first layers row gathers:
 //   e1[i] = relu(W1[pos_i] + sum_{j parent of i} W1[N + pos_j]);  e2 = drop(drop(e1) @ W2)

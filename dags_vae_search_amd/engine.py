@@ -95,6 +95,27 @@ class PaceEngine:
                                  f"1 = label/position row not one-hot, 2 = per-head masks differ, 4 = self masked)")
         return self._records
 
+    def build_records(self, labels: torch.Tensor, preds: torch.Tensor, check: bool = True) -> torch.Tensor:
+        """dvs_build_records: row codec (labels u8 [B,n], preds i16/u16 [B,n]) -> records, all on the device."""
+        _require_cuda(labels, "labels")
+        _require_cuda(preds, "preds")
+        B, n = labels.shape
+        if n != self.n_tokens - 3 or tuple(preds.shape) != (B, n):
+            raise AssertionError(f"Expected {self.n_tokens - 3}, got instead {n}")
+        labels = labels.contiguous().to(torch.uint8)
+        preds = preds.contiguous().to(torch.int16)
+        self.workspace(B, labels.device)
+        self._status.zero_()
+        shape = self.shape(B)
+        dl.check(self.lib, self.lib.dvs_build_records(ctypes.byref(shape), _ptr(labels), _ptr(preds), _ptr(self._records),
+                                                      _ptr(self._status), _stream()), "dvs_build_records")
+        if check:
+            st = int(self._status.item())
+            if st:
+                raise ValueError(f"invalid compact DAG batch (status bits {st:#x}: 1 = label out of range, "
+                                 f"8 = edge not from a lower to a higher vertex id)")
+        return self._records
+
     def loss_forward(self, shape, params: torch.Tensor, eps: Optional[torch.Tensor], losses: torch.Tensor,
                      mu: Optional[torch.Tensor] = None, logvar: Optional[torch.Tensor] = None):
         _require_cuda(params, "parameters")

@@ -25,6 +25,7 @@ from torch import nn
 from . import _lib as dl
 from . import features as feat
 from .engine import PaceEngine
+from .records import CompactBatch
 
 LABEL_KEY = feat.LABEL_KEY
 POSITION_KEY = feat.POSITION_KEY
@@ -267,9 +268,12 @@ class PaceVaeV3(nn.Module):
                                      self.num_heads, self._graph_label_key, self._graph_label_input,
                                      self._graph_label_output, self._graph_label_start, fixed_memory_len, device)
 
-    def _pack(self, features: Dict):
+    def _pack(self, features):
         eng = self._eng()
         dev = self.flat_params.device
+        if isinstance(features, CompactBatch):       # device-side front-end (records.py): no dense features at all
+            eng.build_records(features.labels.to(dev), features.preds.to(dev), check=self.nan_check)
+            return len(features)
         f = {k: features[k].to(dev) for k in ("vertex_label_features", "vertex_position_features",
                                               "adjacency_matrices", "target_masks")}   # pace.py:1981-1984
         eng.pack(f, check=self.nan_check)

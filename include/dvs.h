@@ -70,6 +70,15 @@ int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float
                       const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
                       void* stream);
 
+/* Device-side feature front-end (replaces LabeledDag.from_dict_to_graph src/toolkit/labeled.py:132-154 +
+ * from_labeled_graph_to_pace_graph pace.py:1250-1288 + generate_mask 1307-1343 + prepare_features 1345-1478 + pack):
+ * builds the records straight from the row codec.  labels: device u8 [B][n] (n = n_tokens - 3, l{v} columns);
+ * preds: device u16 [B][n], bit u of preds[b][v] set <=> edge u -> v (the e{v} '0/1' string, u < v).  One thread per
+ * DAG does the PACE wrapping, the FIFO-Kahn topological order (positions[v] = order[v], the reference's quirk), and
+ * the ancestor closure on 16-bit rows.  status bit 0: a label is >= n_classes - 3; bit 3: an edge with u >= v. */
+int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const uint16_t* preds, void* records, int32_t* status,
+                      void* stream);
+
 /* PaceVaeV3.loss_direct forward (pace.py:1974-2035).  eps: optional device [B,32] noise already multiplied
  * by eps_scale (NULL = counter-based normal draws when training).  losses (device f32[4]):
  * {total, recon = -log-likelihood, kld, non-finite flag}.  mu/logvar: optional device [B,32] outputs. */

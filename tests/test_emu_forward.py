@@ -27,3 +27,38 @@ def test_emu_forward_eval_matches_oracle(name, B):
     assert rel(losses[1], recon) < 1e-4
     assert rel(losses[0], total) < 1e-4
     assert losses[3] == 0.0
+
+
+@pytest.mark.parametrize("n,card,seed", [(12, 12, 3), (8, 8, 4), (11, 11, 5), (5, 2, 6)])
+def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
+    """Device-side front-end (dvs_build_records) == dvs_pack_features(oracle dense features), byte for byte."""
+    import ctypes
+    from dags_vae_search_amd import _lib as dl
+    from dags_vae_search_amd.records import encode_graphs
+    from tests.emu.harness import emu, ptr
+    graphs = ofeat.synthetic_dags(n, card, 96, seed=seed)
+    B = len(graphs)
+    lib = emu()
+    shape = dl.make_shape(B, n + 3, card + 3)
+    f = ofeat.dense_features(graphs, card)
+    rec_a = np.zeros(B * dl.RECORD_BYTES, np.uint8)
+    status = np.zeros(1, np.int32)
+    tm = np.ascontiguousarray(f["target_masks"]).astype(np.uint8)
+    assert lib.dvs_pack_features(ctypes.byref(shape), ptr(f["vertex_label_features"]), ptr(f["vertex_position_features"]),
+                                 ptr(f["adjacency_matrices"]), ptr(tm), ptr(rec_a), ptr(status), None) == 0
+    assert status[0] == 0
+    cb = encode_graphs(graphs, n)
+    lab = np.ascontiguousarray(cb.labels.numpy())
+    pr = np.ascontiguousarray(cb.preds.numpy())
+    rec_b = np.zeros(B * dl.RECORD_BYTES, np.uint8)
+    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab), ptr(pr), ptr(rec_b), ptr(status), None) == 0
+    assert status[0] == 0
+    assert np.array_equal(rec_a, rec_b)
+    # non-identity positions occur (the order quirk is exercised)
+    pos = rec_b.reshape(B, 96)[:, 16:16 + n + 3]
+    assert (pos != np.arange(n + 3)).any() or n < 6
+    # bad label -> status bit 0
+    lab2 = lab.copy()
+    lab2[0, 0] = card + 5
+    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab2), ptr(pr), ptr(rec_b), ptr(status), None) == 0
+    assert status[0] & 1

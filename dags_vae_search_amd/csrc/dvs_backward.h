@@ -202,6 +202,116 @@ __device__ __forceinline__ void dvs_ln_bwd(f4 (&dx)[4], const f4 (&xhat)[4], flo
         for (int kk = 0; kk < 4; ++kk) dx[t][kk] = rstd * (dx[t][kk] - s1 - xhat[t][kk] * s2);
 }
 
+// ---- cooperative weight gradients (8-wave backward kernels) --------------------------------------------------------
+// A wave that accumulated a whole 64x64 dW for its own DAGs needs 64 accumulator registers per matrix, which pins the
+// backward kernels at one wave per SIMD.  Instead the 8 waves of a workgroup form two independent GROUPS of four
+// (waves 0-3 and 4-7; a SIMD hosts one wave of each, so the groups' instruction streams interleave on every SIMD).
+// Every wave parks the two operand tiles of its DAG row-major ([token][feature], stride DVS_LD) in its LDS slots, the
+// group synchronises on its own LDS counter (an s_barrier would lock both groups into the same phase and forfeit the
+// MFMA/VALU overlap), and wave w accumulates rows 16*(w&3).. of dW over the 4 DAGs of its group: same MFMA count,
+// 16 accumulator registers per matrix instead of 64.
+struct DvsGroup {
+    int* counter;      // LDS word of this wave's group
+    int target;        // arrivals expected at the next barrier
+};
+__device__ __forceinline__ void dvs_group_barrier(DvsGroup& G, const Lane& L) {
+    G.target += 4;
+#ifdef DVS_EMU
+    if (L.lane == 0) atomicAdd(G.counter, 1);
+    while (__atomic_load_n(G.counter, __ATOMIC_RELAXED) < G.target) emu::yield();
+    (void)emu::exchange(0, 0);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's slot writes are visible (lgkmcnt(0))
+    if (L.lane == 0) atomicAdd(G.counter, 1);
+    // bounded spin (~1 s): a lost arrival must never hang the GPU; parity tests catch the wrong result it would give
+    for (int spins = 0; __hip_atomic_load(G.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < G.target &&
+                        spins < (1 << 24); ++spins)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+// Wave d's dY tile is at abase + d*stride, its X tile at bbase + d*stride (floats);
+// acc[it][reg] = dW[16*(wave&3) + 4g + reg][16*it + r], summed over the DAGs of this wave's group.
+__device__ __forceinline__ void dvs_coop_dw(f4 (&acc)[4], const float* abase, const float* bbase, int stride, const Lane& L) {
+    const int ot = L.wave & 3, d0 = L.wave & 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float* sa = abase + (d0 + d) * stride + (4 * L.g) * DVS_LD + L.r;
+        const float* sb = bbase + (d0 + d) * stride + (4 * L.g) * DVS_LD + L.r;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float av = sa[kk * DVS_LD + 16 * ot];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma(av, sb[kk * DVS_LD + 16 * it], acc[it]);
+        }
+        DVS_SCHED_FENCE();
+    }
+}
+// park a T-layout tile row-major in a slot
+__device__ __forceinline__ void dvs_park_T(float* slot, const f4 (&v)[4], const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *(f4*)(slot + L.r * DVS_LD + 16 * t + 4 * L.g) = v[t];
+}
+// park an N-layout tile row-major in a slot
+__device__ __forceinline__ void dvs_park_N(float* slot, const f4 (&v)[4], const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float* p = slot + (4 * L.g) * DVS_LD + 16 * t + L.r;
+        p[0] = v[t][0];
+        p[DVS_LD] = v[t][1];
+        p[2 * DVS_LD] = v[t][2];
+        p[3 * DVS_LD] = v[t][3];
+    }
+}
+// sum over the 16 token rows of column `lane` of a parked tile (bias / LayerNorm-parameter gradients: 1 register)
+__device__ __forceinline__ float dvs_colsum(const float* slot, const Lane& L) {
+    float s = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) s += slot[rr * DVS_LD + L.lane];
+    return s;
+}
+// Add the two groups' partial dW (rows 16*(wave&3).. each) and write the 64x64 result to the slab.  buf: 4096 floats of
+// LDS.  Contains workgroup barriers: call from all 8 waves.
+__device__ __forceinline__ void dvs_coop_store(float* buf, float* dst, const f4 (&acc)[4], const Lane& L, bool rperm = false,
+                                               bool cperm = false, int ld_dst = 64) {
+    const int ot = L.wave & 3;
+    if (L.wave < 4) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) buf[(16 * ot + 4 * L.g + reg) * 64 + 16 * it + L.r] = acc[it][reg];
+    }
+    __syncthreads();
+    if (L.wave >= 4) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * ot + 4 * L.g + reg, col = 16 * it + L.r;
+                dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = acc[it][reg] + buf[row * 64 + col];
+            }
+    }
+    __syncthreads();
+}
+// LayerNorm backward without the parameter-gradient accumulation (done by column sums of parked tiles)
+__device__ __forceinline__ void dvs_ln_bwd_core(f4 (&dx)[4], const f4 (&xhat)[4], float rstd, const float* lg, const Lane& L) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f4 g = dvs_vecT(lg, t, L);
+        dx[t] *= g;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s1 += dx[t][kk];
+            s2 += dx[t][kk] * xhat[t][kk];
+        }
+    }
+    s1 = dvs_sum_g(s1) * (1.f / 64.f);
+    s2 = dvs_sum_g(s2) * (1.f / 64.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dx[t] = (dx[t] - s1 - xhat[t] * s2) * rstd;
+}
+
 __device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L,
                                               const float* slot = nullptr) {
     if (slot) dvs_slot_tile(g, slot, L);

@@ -6,7 +6,7 @@
 // pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
 // ---------------------------------------------------------------------------------------------------------
 struct FfnBLds {
-    float *W1, *W2, *b1, *b2, *lg, *lb, *og, *ob, *scr;
+    float *W1, *W2, *b1, *b2, *lg, *lb, *og, *ob, *slots;
 };
 __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     FfnBLds l;
@@ -18,12 +18,14 @@ __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     l.lb = l.lg + 64;
     l.og = l.lb + 64;
     l.ob = l.og + 64;
-    l.scr = l.ob + 64;
+    l.slots = l.ob + 64;
     return l;
 }
-static size_t ffnb_lds_floats(int nwaves) { return 128 * DVS_LD + 6 * 64 + (size_t)nwaves * (DVS_SCR + 3 * DVS_TILE); }
+static size_t ffnb_lds_floats() { return 128 * DVS_LD + 6 * 64 + (size_t)8 * 2 * DVS_SCR + 16; }
 
-__global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
+// 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
+// (dvs_coop_dw): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
+__global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
@@ -38,45 +40,41 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_stage_vector(l.og, a.own.g, 64);
         dvs_stage_vector(l.ob, a.own.b, 64);
     }
+    int* gcount = (int*)(l.slots + 8 * 2 * DVS_SCR);
+    if (threadIdx.x < 2) gcount[threadIdx.x] = 0;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
-    const int N = a.dims.N;
-    float* scr = l.scr + L.wave * DVS_SCR;
-    float* pf = l.scr + L.nwaves * DVS_SCR + L.wave * 3 * DVS_TILE;    // LDS-DMA landing zone: x, d pre, own pre
-    f4 dW1[4][4], dW2[4][4], db1[4], db2[4], dgam[4], dbet[4], dog[4], dob[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        db1[i] = db2[i] = dgam[i] = dbet[i] = dog[i] = dob[i] = f4_zero();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dW1[i][j] = dW2[i][j] = f4_zero();
-    }
-    const int Bl = a.dims.B;
-    const int stride = gridDim.x * L.nwaves;
-    int dag = blockIdx.x * L.nwaves + L.wave;
-    if (dag < Bl) {
-        dvs_prefetch_tile(pf, a.xin, dag, L);
-        dvs_prefetch_tile(pf + DVS_TILE, a.gpre, dag, L);
-        if (a.own_pre) dvs_prefetch_tile(pf + 2 * DVS_TILE, a.own_pre, dag, L);
-    }
-    for (; dag < Bl; dag += stride) {
-        dvs_prefetch_wait();
-        f4 x[4], xhat[4];
+    const int N = a.dims.N, B = a.dims.B;
+    float* sA = l.slots + L.wave * 2 * DVS_SCR;
+    float* sB = sA + DVS_SCR;
+    DvsGroup G = {gcount + (L.wave >> 2), 0};
+    f4 aW1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, aW2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+    float vb1 = 0.f, vb2 = 0.f, vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;    // lane = feature
+    for (int base = blockIdx.x * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const int Nl = live ? N : 0;                       // a wave without a DAG carries all-zero tiles
+        f4 x[4], xhat[4], gp[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L, pf);
-        f4 gp[4];
-        dvs_load_grad(gp, a.gpre, dag, N, L, pf + DVS_TILE);
-        f4 po[4], pxh[4];
-        float prstd = 1.f;
-        if (a.own_pre) dvs_load_x<true>(po, pxh, prstd, a.own_pre, a.own, l.og, l.ob, dag, N, L, pf + 2 * DVS_TILE);
-        dvs_slot_release();
-        if (dag + stride < Bl) {
-            dvs_prefetch_tile(pf, a.xin, dag + stride, L);
-            dvs_prefetch_tile(pf + DVS_TILE, a.gpre, dag + stride, L);
-            if (a.own_pre) dvs_prefetch_tile(pf + 2 * DVS_TILE, a.own_pre, dag + stride, L);
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
+        dvs_load_grad(gp, a.gpre, dg, Nl, L);
+        if (a.own_pre) {   // incoming gradient is w.r.t. LN_own(pre_own): pull back to d(pre_own)
+            f4 po[4], pxh[4], t0[4];
+            float prstd;
+            dvs_load_x<true>(po, pxh, prstd, a.own_pre, a.own, l.og, l.ob, dg, Nl, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) t0[t] = gp[t] * pxh[t];
+            dvs_park_T(sA, t0, L);
+            dvs_park_T(sB, gp, L);
+            dvs_wave_sync();
+            vog += dvs_colsum(sA, L);
+            vob += dvs_colsum(sB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(gp, pxh, prstd, l.og, L);
         }
-        if (a.own_pre) dvs_ln_bwd(gp, pxh, prstd, l.og, dog, dob, L);   // d(LN_own(pre_own)) -> d(pre_own)
-        const uint32_t gdag = a.dims.dag_offset + dag;
+        const uint32_t gdag = a.dims.dag_offset + (uint32_t)dg;
         const uint32_t khid = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag);
         const uint32_t kpost = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag);
         // recompute hidden
@@ -87,19 +85,20 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) hd[t][kk] = fmaxf(hpre[t][kk], 0.f);
+            for (int kk = 0; kk < 4; ++kk) hd[t][kk] = (live && L.r < N) ? fmaxf(hpre[t][kk], 0.f) : 0.f;
         dvs_dropout_tile(hd, khid, D, L);
         // dy = d(W2 h + b2) = dropout-mask(post) applied to d pre
         f4 dy[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dy[t] = gp[t];
         dvs_dropout_tile(dy, kpost, D, L);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) db2[t] += dy[t];
-        f4 dyN[4], hN[4];
-        dvs_t2n<4>(dyN, dy, scr, L);
-        dvs_t2n<4>(hN, hd, scr, L);
-        dvs_outer_acc<4, 4>(dW2, dyN, hN);
+        // ---- dW2 += dy^T hd, db2 += sum dy --------------------------------------------------------------------------
+        dvs_park_T(sA, dy, L);
+        dvs_park_T(sB, hd, L);
+        dvs_wave_sync();
+        vb2 += dvs_colsum(sA, L);
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aW2, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
         dvs_mat_Tt<4, 4>(dh, dy, l.W2, DVS_LD, 0, L);
         dvs_dropout_tile(dh, khid, D, L);
@@ -107,54 +106,58 @@ __global__ __launch_bounds__(256) void k_ffn_bwd(FfnBwdArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) dh[t][kk] = hpre[t][kk] > 0.f ? dh[t][kk] : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) db1[t] += dh[t];
-        f4 dhN[4], xN[4];
-        dvs_t2n<4>(dhN, dh, scr, L);
-        dvs_t2n<4>(xN, x, scr, L);
-        dvs_outer_acc<4, 4>(dW1, dhN, xN);
+        dvs_group_barrier(G, L);
+        // ---- dW1 += dh^T x, db1 += sum dh ----------------------------------------------------------------------------
+        dvs_park_T(sA, dh, L);
+        dvs_park_T(sB, x, L);
+        dvs_wave_sync();
+        vb1 += dvs_colsum(sA, L);
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aW1, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
         f4 dx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] = gp[t];
         dvs_mat_Tt<4, 4>(dx, dh, l.W1, DVS_LD, 0, L);
-        if (a.ln.stats) dvs_ln_bwd(dx, xhat, rstd, l.lg, dgam, dbet, L);
-        dvs_store_tile(a.gout, dag, dx, L);
+        dvs_group_barrier(G, L);
+        if (a.ln.stats) {
+            f4 t0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) t0[t] = dx[t] * xhat[t];
+            dvs_park_T(sA, t0, L);
+            dvs_park_T(sB, dx, L);
+            dvs_wave_sync();
+            vgam += dvs_colsum(sA, L);
+            vbet += dvs_colsum(sB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(dx, xhat, rstd, l.lg, L);
+        }
+        if (live) dvs_store_tile(a.gout, dag, dx, L);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* rW1 = (float*)smem;
-    float* rW2 = rW1 + DVS_RED_MAT;
-    float* rv = rW2 + DVS_RED_MAT;               // 6 vectors
-    float* es = rv + 6 * DVS_RED_VEC + L.wave * DVS_SCR;
-    dvs_stage_dw<4, 4>(rW1, dW1, L);
-    dvs_stage_dw<4, 4>(rW2, dW2, L);
-    dvs_stage_vec<4>(rv, db1, es, L);
-    dvs_stage_vec<4>(rv + DVS_RED_VEC, db2, es, L);
-    dvs_stage_vec<4>(rv + 2 * DVS_RED_VEC, dgam, es, L);
-    dvs_stage_vec<4>(rv + 3 * DVS_RED_VEC, dbet, es, L);
-    dvs_stage_vec<4>(rv + 4 * DVS_RED_VEC, dog, es, L);
-    dvs_stage_vec<4>(rv + 5 * DVS_RED_VEC, dob, es, L);
+    dvs_coop_store((float*)smem, slab + a.o_l1_w, aW1, L);
+    dvs_coop_store((float*)smem, slab + a.o_l2_w, aW2, L);
+    float* red = (float*)smem;                        // [8 waves][6][64]
+    red[(L.wave * 6 + 0) * 64 + L.lane] = vb1;
+    red[(L.wave * 6 + 1) * 64 + L.lane] = vb2;
+    red[(L.wave * 6 + 2) * 64 + L.lane] = vgam;
+    red[(L.wave * 6 + 3) * 64 + L.lane] = vbet;
+    red[(L.wave * 6 + 4) * 64 + L.lane] = vog;
+    red[(L.wave * 6 + 5) * 64 + L.lane] = vob;
     __syncthreads();
-    dvs_flush_dw<4, 4>(rW1, slab + a.o_l1_w, L);
-    dvs_flush_dw<4, 4>(rW2, slab + a.o_l2_w, L);
-    dvs_flush_vec<4>(rv, slab + a.o_l1_b, L);
-    dvs_flush_vec<4>(rv + DVS_RED_VEC, slab + a.o_l2_b, L);
-    if (a.o_ln_g >= 0) {
-        dvs_flush_vec<4>(rv + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
-        dvs_flush_vec<4>(rv + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
-    }
-    if (a.o_own_g >= 0) {
-        dvs_flush_vec<4>(rv + 4 * DVS_RED_VEC, slab + a.o_own_g, L);
-        dvs_flush_vec<4>(rv + 5 * DVS_RED_VEC, slab + a.o_own_b, L);
+    if (threadIdx.x < 6 * 64) {
+        const int k = threadIdx.x >> 6, f = threadIdx.x & 63;
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[(w * 6 + k) * 64 + f];
+        const int64_t off = k == 0 ? a.o_l1_b : k == 1 ? a.o_l2_b : k == 2 ? a.o_ln_g : k == 3 ? a.o_ln_b : k == 4 ? a.o_own_g : a.o_own_b;
+        if (off >= 0) slab[off + f] = s;
     }
 }
 
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = ffnb_lds_floats(4) * 4;
-    const size_t red = (2 * DVS_RED_MAT + 6 * DVS_RED_VEC + 4 * DVS_SCR) * 4;
-    if (lds < red) lds = red;
+    const size_t lds = ffnb_lds_floats() * 4;
     DVS_SET_LDS(k_ffn_bwd, lds);
-    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -162,122 +165,120 @@ void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
 //   dX^T = sum_p W_p^T dY_p^T (+ residual) ; dW_p += dY_p(N) (x) X(N) ; db_p += sum_tok dY_p ; then the producing
 //   sublayer's LayerNorm backward.  Used for self-attention (NPROJ=3), cross-attention q (1) and k,v (2, X = memory).
 // ---------------------------------------------------------------------------------------------------------
+// 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw):
+// per wave 16 accumulator registers per projection, ~130 VGPRs, two waves per SIMD.  LDS slots per wave: X (kept for
+// all projections of the DAG) and two alternating dY slots, so one group barrier per projection + one per DAG.
 template <int NPROJ>
-__global__ __launch_bounds__(256) void k_proj_bwd(ProjBwdArgs a) {
+__global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
     DVS_DYN_LDS(smem);
     float* W = (float*)smem;                       // [64*NPROJ][LD]
     float* lg = W + 64 * NPROJ * DVS_LD;
     float* lb = lg + 64;
-    float* scr0 = lb + 64;
+    float* slots = lb + 64;                        // per wave 3 tiles: A0, A1 (alternating dY) and B (X)
+    int* gcount = (int*)(slots + 8 * 3 * DVS_SCR);
     if (a.slot_order) dvs_stage_matrix_perm(W, DVS_LD, a.w, 64, 64 * NPROJ, 64, true, false);
     else dvs_stage_matrix(W, DVS_LD, a.w, 64, 64 * NPROJ, 64);
     if (a.ln.stats) {
         dvs_stage_vector(lg, a.ln.g, 64);
         dvs_stage_vector(lb, a.ln.b, 64);
     }
+    if (threadIdx.x < 2) gcount[threadIdx.x] = 0;
     __syncthreads();
     const Lane L = dvs_lane();
-    const int N = a.dims.N;
-    float* scr = scr0 + L.wave * DVS_SCR;
-    float* pf = scr0 + L.nwaves * DVS_SCR + L.wave * (NPROJ + 2) * DVS_TILE;   // LDS-DMA landing zone: x, residual, dY_p
-    f4 dW[NPROJ][4][4], db[NPROJ][4], dgam[4], dbet[4];
+    const int N = a.dims.N, B = a.dims.B;
+    float* myA0 = slots + L.wave * 3 * DVS_SCR;
+    float* myA1 = myA0 + DVS_SCR;
+    float* myB = myA0 + 2 * DVS_SCR;
+    DvsGroup G = {gcount + (L.wave >> 2), 0};
+    f4 aW[NPROJ][4];
+    float vb[NPROJ], vgam = 0.f, vbet = 0.f;
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p)
+    for (int p = 0; p < NPROJ; ++p) {
+        vb[p] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            db[p][i] = f4_zero();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dW[p][i][j] = f4_zero();
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dgam[i] = dbet[i] = f4_zero();
-    const int stride = gridDim.x * L.nwaves;
-    int dag = blockIdx.x * L.nwaves + L.wave;
-    auto request = [&](int d) {
-        dvs_prefetch_tile(pf, a.xin, d, L);
-        if (a.gres) dvs_prefetch_tile(pf + DVS_TILE, a.gres, d, L);
-#pragma unroll
-        for (int p = 0; p < NPROJ; ++p) dvs_prefetch_tile(pf + (2 + p) * DVS_TILE, a.gy[p], d, L);
-    };
-    if (dag < a.dims.B) request(dag);
-    for (; dag < a.dims.B; dag += stride) {
-        dvs_prefetch_wait();
-        f4 x[4], xhat[4];
+        for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
+    }
+    for (int base = blockIdx.x * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const int Nl = live ? N : 0;
+        f4 x[4], xhat[4], dx[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dag, N, L, pf);
-        f4 dy[NPROJ][4], dx[4];
-#pragma unroll
-        for (int p = 0; p < NPROJ; ++p) dvs_load_grad(dy[p], a.gy[p], dag, N, L, pf + (2 + p) * DVS_TILE);
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dg, Nl, L);
         if (a.gres) {
-            dvs_load_grad(dx, a.gres, dag, N, L, pf + DVS_TILE);
+            dvs_load_grad(dx, a.gres, dg, Nl, L);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
         }
-        dvs_slot_release();
-        if (dag + stride < a.dims.B) request(dag + stride);
-        f4 xN[4];
-        dvs_t2n<4>(xN, x, scr, L);
+        dvs_park_T(myB, x, L);
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
-            f4 dyN[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) db[p][t] += dy[p][t];
-            dvs_t2n<4>(dyN, dy[p], scr, L);
-            dvs_outer_acc<4, 4>(dW[p], dyN, xN);
-            dvs_mat_Tt<4, 4>(dx, dy[p], W, DVS_LD, 64 * p, L);
+            float* mine = (p & 1) ? myA1 : myA0;
+            f4 dy[4];
+            dvs_load_grad(dy, a.gy[p], dg, Nl, L);
+            dvs_park_T(mine, dy, L);
+            dvs_wave_sync();
+            vb[p] += dvs_colsum(mine, L);
+            dvs_group_barrier(G, L);
+            dvs_coop_dw(aW[p], slots + (p & 1) * DVS_SCR, slots + 2 * DVS_SCR, 3 * DVS_SCR, L);
+            dvs_mat_Tt<4, 4>(dx, dy, W, DVS_LD, 64 * p, L);
         }
-        if (a.ln.stats) dvs_ln_bwd(dx, xhat, rstd, lg, dgam, dbet, L);
-        if (a.accumulate_out) {
-            f4 old[4];
-            dvs_load_tile(old, a.gout, dag, L);
+        dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
+        if (a.ln.stats) {
+            f4 t0[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dx[t] += old[t];
+            for (int t = 0; t < 4; ++t) t0[t] = dx[t] * xhat[t];
+            dvs_park_T(myA0, t0, L);
+            dvs_park_T(myB, dx, L);
+            dvs_wave_sync();
+            vgam += dvs_colsum(myA0, L);
+            vbet += dvs_colsum(myB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(dx, xhat, rstd, lg, L);
         }
-        dvs_store_tile(a.gout, dag, dx, L);
+        if (live) {
+            if (a.accumulate_out) {
+                f4 old[4];
+                dvs_load_tile(old, a.gout, dag, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dx[t] += old[t];
+            }
+            dvs_store_tile(a.gout, dag, dx, L);
+        }
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* rW = (float*)smem;                     // up to 2 matrices per pass
-    float* rv = rW + 2 * DVS_RED_MAT;             // NPROJ + 2 vectors
-    float* es = rv + 5 * DVS_RED_VEC + L.wave * DVS_SCR;
+    const bool so = a.slot_order != 0;
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) dvs_stage_vec<4>(rv + p * DVS_RED_VEC, db[p], es, L);
-    dvs_stage_vec<4>(rv + NPROJ * DVS_RED_VEC, dgam, es, L);
-    dvs_stage_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, dbet, es, L);
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_store((float*)smem, slab + a.o_w + 4096 * p, aW[p], L, so, false);
+    float* red = (float*)smem;                        // [8 waves][NPROJ + 2][64]
 #pragma unroll
-    for (int p0 = 0; p0 < NPROJ; p0 += 2) {
-        if (p0 > 0) __syncthreads();
-        dvs_stage_dw<4, 4>(rW, dW[p0], L);
-        if (p0 + 1 < NPROJ) dvs_stage_dw<4, 4>(rW + DVS_RED_MAT, dW[p0 + 1 < NPROJ ? p0 + 1 : p0], L);
-        __syncthreads();
-        const bool so = a.slot_order != 0;
-        dvs_flush_dw<4, 4>(rW, slab + a.o_w + 4096 * p0, L, 64, 64, 64, so, false);
-        if (p0 + 1 < NPROJ) dvs_flush_dw<4, 4>(rW + DVS_RED_MAT, slab + a.o_w + 4096 * (p0 + 1), L, 64, 64, 64, so, false);
-        if (p0 == 0) {
-#pragma unroll
-            for (int p = 0; p < NPROJ; ++p) dvs_flush_vec<4>(rv + p * DVS_RED_VEC, slab + a.o_b + 64 * p, L, 64, so);
-            if (a.o_ln_g >= 0) {
-                dvs_flush_vec<4>(rv + NPROJ * DVS_RED_VEC, slab + a.o_ln_g, L);
-                dvs_flush_vec<4>(rv + (NPROJ + 1) * DVS_RED_VEC, slab + a.o_ln_b, L);
-            }
-        }
+    for (int p = 0; p < NPROJ; ++p) red[(L.wave * (NPROJ + 2) + p) * 64 + L.lane] = vb[p];
+    red[(L.wave * (NPROJ + 2) + NPROJ) * 64 + L.lane] = vgam;
+    red[(L.wave * (NPROJ + 2) + NPROJ + 1) * 64 + L.lane] = vbet;
+    __syncthreads();
+    if (threadIdx.x < (NPROJ + 2) * 64) {
+        const int k = threadIdx.x >> 6, f = threadIdx.x & 63;
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[(w * (NPROJ + 2) + k) * 64 + f];
+        if (k < NPROJ) slab[a.o_b + 64 * k + (so ? dvs_pi(f) : f)] = s;
+        else if (a.o_ln_g >= 0) slab[(k == NPROJ ? a.o_ln_g : a.o_ln_b) + f] = s;
     }
 }
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
-    const size_t lds = ((size_t)64 * nproj * DVS_LD + 128 + 4 * DVS_SCR + 4 * (size_t)(nproj + 2) * DVS_TILE) * 4;
-    const size_t lds_min = (2 * DVS_RED_MAT + 5 * DVS_RED_VEC + 4 * DVS_SCR) * 4;   // epilogue staging
-    const size_t bytes = lds > lds_min ? lds : lds_min;
+    const size_t bytes = ((size_t)64 * nproj * DVS_LD + 128 + (size_t)8 * 3 * DVS_SCR + 16) * 4;
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);
-        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(512), bytes, st, a);
     } else if (nproj == 2) {
         DVS_SET_LDS(k_proj_bwd<2>, bytes);
-        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(512), bytes, st, a);
     } else {
         DVS_SET_LDS(k_proj_bwd<1>, bytes);
-        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(256), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(512), bytes, st, a);
     }
 }
 

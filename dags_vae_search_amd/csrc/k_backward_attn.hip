@@ -10,7 +10,8 @@
 #include "dvs_backward.h"
 
 struct AttnBLds {
-    float *Win, *Wout, *inb, *outb, *lg, *lb, *scr;
+    float *Win, *Wout, *inb, *outb, *lg, *lb, *slots, *stats;
+    int* gcount;
 };
 __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
     AttnBLds l;
@@ -20,10 +21,12 @@ __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
-    l.scr = l.lb + 64;
+    l.slots = l.lb + 64;                       // per wave: A (d y, row-major) and B (transpose scratch, then O)
+    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
+    l.gcount = (int*)(l.stats + 8 * 128);
     return l;
 }
-static size_t attnb_lds_floats(int nwaves) { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)nwaves * (DVS_SCR + 3 * DVS_TILE); }
+static size_t attnb_lds_floats() { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16; }
 
 // dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
 // reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
@@ -49,7 +52,10 @@ __device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, cons
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
+// 8 waves per workgroup in two independent groups of four (dvs_backward.h); one DAG per wave per iteration.  The
+// out-projection gradient is accumulated cooperatively from the parked d y and O tiles, d q / d k / d v tiles are stored
+// as soon as their head pair is finished, so a wave stays within 256 registers and two waves share each SIMD.
+__global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnBLds l = attnb_lds(smem);
     dvs_stage_matrix_perm(l.Win, DVS_LD, a.in_w, 64, 192, 64, true, false);    // head-aligned slot order (dvs_device.h)
@@ -60,43 +66,33 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
         dvs_stage_vector(l.lg, a.ln.g, 64);
         dvs_stage_vector(l.lb, a.ln.b, 64);
     }
+    if (threadIdx.x < 2) l.gcount[threadIdx.x] = 0;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
-    const int N = a.dims.N;
-    float* scr = l.scr + L.wave * DVS_SCR;
-    float* pf = l.scr + L.nwaves * DVS_SCR + L.wave * 3 * DVS_TILE;   // LDS-DMA landing zone: x, kv, d pre
+    const int N = a.dims.N, B = a.dims.B;
+    float* sA = l.slots + L.wave * 2 * DVS_SCR;
+    float* sB = sA + DVS_SCR;
+    float* st = l.stats + L.wave * 128;
+    DvsGroup G = {l.gcount + (L.wave >> 2), 0};
     const float scale = 0.35355339059327373f;
-    f4 dWo[4][4], dbo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dbo[i] = f4_zero();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dWo[i][j] = f4_zero();
-    }
-    const int stride = gridDim.x * L.nwaves;
-    int dag = blockIdx.x * L.nwaves + L.wave;
-    auto request = [&](int d) {
-        dvs_prefetch_tile(pf, a.xin, d, L);
-        if (a.kv) dvs_prefetch_tile(pf + DVS_TILE, a.kv, d, L);
-        dvs_prefetch_tile(pf + 2 * DVS_TILE, a.gpre, d, L);
-    };
-    if (dag < a.dims.B) request(dag);
-    for (; dag < a.dims.B; dag += stride) {
-        dvs_prefetch_wait();
-        const uint32_t gdag = a.dims.dag_offset + dag;
+    f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+    float vbo = 0.f;
+    for (int base = blockIdx.x * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const int Nl = live ? N : 0;
+        const uint32_t gdag = a.dims.dag_offset + (uint32_t)dg;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        f4 q[4], k[4], v[4], dy[4];
-        dvs_load_grad(dy, a.gpre, dag, N, L, pf + 2 * DVS_TILE);
-        const unsigned allowed_r = a.rec[dag].allowed[L.r];
+        const unsigned allowed_r = live ? a.rec[dg].allowed[L.r] : (1u << L.r);
+        f4 q[4], k[4], v[4];
         {
             f4 x[4], kv[4], dummy[4];
             float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L, pf);
-            if (a.kv) dvs_slot_tile(kv, pf + DVS_TILE, L);
-            dvs_slot_release();
-            if (dag + stride < a.dims.B) request(dag + stride);
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
             if (a.kv) {
+                dvs_load_tile(kv, a.kv, dg, L);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) kv[t] = x[t];
@@ -113,18 +109,22 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) q[t] *= scale;
         }
-        dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
+        f4 qN[4], kN[4], vT[4], dOT[4], dON[4];
+        {
+            f4 dy[4];
+            dvs_load_grad(dy, a.gpre, dg, Nl, L);
+            dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
+            dvs_park_T(sA, dy, L);                     // stays parked until the cooperative dWo below
+            dvs_wave_sync();
+            vbo += dvs_colsum(sA, L);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dbo[t] += dy[t];
-        f4 qN[4], kN[4], vT[4], dyN[4], dOT[4], dON[4];
-        dvs_t2n<4>(qN, q, scr, L);
-        dvs_t2n<4>(kN, k, scr, L);
-        dvs_n2t<4>(vT, v, scr, L);
-        dvs_t2n<4>(dyN, dy, scr, L);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dOT[t] = f4_zero();
-        dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
-        dvs_t2n<4>(dON, dOT, scr, L);
+            for (int t = 0; t < 4; ++t) dOT[t] = f4_zero();
+            dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
+        }
+        dvs_t2n<4>(qN, q, sB, L);
+        dvs_t2n<4>(kN, k, sB, L);
+        dvs_n2t<4>(vT, v, sB, L);
+        dvs_t2n<4>(dON, dOT, sB, L);
 
         const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
         bool ok[4];
@@ -134,40 +134,34 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
             ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
             al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
         }
-        f4 oN[4], dq[4], dk[4], dv[4];
-        // Heads are processed four at a time (tiles 2*half, 2*half+1): enough independent chains to cover the MFMA and
-        // cross-lane latencies, half the temporaries of an all-heads pass (the kernel sits at the 512-register limit).
+        // One feature tile (= one head pair) per pass: the smallest set of live temporaries; the second wave on the SIMD
+        // supplies the instruction-level parallelism that a wider pass would.
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int t = 0; t < 4; ++t) {
             // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) --------------------------------------------
-            f4 pT[4], dsT[4];
-            float lse[4], delta[4];
+            f4 pT[2], dsT[2];
+            float lse[2], delta[2];
             {
-                f4 sT[4];
+                f4 sT[2] = {f4_zero(), f4_zero()};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sT[u] = f4_zero();
+                for (int kk = 0; kk < 2; ++kk) {
+                    sT[0] = dvs_mfma(k[t][kk], q[t][kk], sT[0]);
+                    sT[1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[1]);
+                }
+                float m[2], den[2];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 2 * half + tt;
-                        sT[2 * tt] = dvs_mfma(k[t][kk], q[t][kk], sT[2 * tt]);
-                        sT[2 * tt + 1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[2 * tt + 1]);
-                    }
-                float m[4], den[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, sT[u][reg]) : mx;
                     m[u] = mx;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 16));
+                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 16));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 32));
+                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 32));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     float sum = 0.f;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
@@ -177,46 +171,42 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
                     den[u] = sum;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) den[u] += __shfl_xor(den[u], 16);
+                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) den[u] += __shfl_xor(den[u], 32);
+                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 32);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     pT[u] *= (1.0f / den[u]);
                     lse[u] = m[u] + __logf(den[u]);
                 }
             }
             {
-                f4 mk[4], dpT[4];
+                f4 mk[2], dpT[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    mk[u] = mask_T(kprob, 4 * half + u, D, L);
+                for (int u = 0; u < 2; ++u) {
+                    mk[u] = mask_T(kprob, 2 * t + u, D, L);
                     dpT[u] = f4_zero();
                 }
-                // O (N-layout, for dWo) = P' V: both heads of a tile on all 16 slot columns, per-lane head select
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int t = 2 * half + tt;
+                // O = P' V (N-layout, columns = slots, per-lane head select), parked row-major in slot B for dWo
+                {
                     f4 oa = f4_zero(), ob = f4_zero();
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
-                        oa = dvs_mfma(pT[2 * tt][kk] * mk[2 * tt][kk], v[t][kk], oa);
-                        ob = dvs_mfma(pT[2 * tt + 1][kk] * mk[2 * tt + 1][kk], v[t][kk], ob);
+                        oa = dvs_mfma(pT[0][kk] * mk[0][kk], v[t][kk], oa);
+                        ob = dvs_mfma(pT[1][kk] * mk[1][kk], v[t][kk], ob);
                     }
+                    float* po = sB + (4 * L.g) * DVS_LD + 16 * t + L.r;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) oN[t][reg] = hsel ? ob[reg] : oa[reg];
+                    for (int reg = 0; reg < 4; ++reg) po[reg * DVS_LD] = hsel ? ob[reg] : oa[reg];
                 }
                 // dP^T = V dO^T
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < 2; ++kk) {
+                    dpT[0] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[0]);
+                    dpT[1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[1]);
+                }
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 2 * half + tt;
-                        dpT[2 * tt] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[2 * tt]);
-                        dpT[2 * tt + 1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[2 * tt + 1]);
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     dpT[u] *= mk[u];
                     float dl = 0.f;
 #pragma unroll
@@ -224,57 +214,50 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
                     delta[u] = dl;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) delta[u] += __shfl_xor(delta[u], 16);
+                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) delta[u] += __shfl_xor(delta[u], 32);
+                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 32);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) dsT[u][reg] = pT[u][reg] * (dpT[u][reg] - delta[u]);
             }
-            // dq^T = K^T dS^T: all 16 slot rows per head, merged by register (rows reg 0,1 <-> first head of the tile)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * half + tt;
+            // dq^T = K^T dS^T: all 16 slot rows per head, merged by register; stored at once (scaled by 1/sqrt(dh))
+            {
                 f4 qa = f4_zero(), qb = f4_zero();
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    qa = dvs_mfma(kN[t][kk], dsT[2 * tt][kk], qa);
-                    qb = dvs_mfma(kN[t][kk], dsT[2 * tt + 1][kk], qb);
+                    qa = dvs_mfma(kN[t][kk], dsT[0][kk], qa);
+                    qb = dvs_mfma(kN[t][kk], dsT[1][kk], qb);
                 }
-                dq[t] = f4{qa[0], qa[1], qb[2], qb[3]};
+                const f4 dq = f4{qa[0], qa[1], qb[2], qb[3]} * scale;
+                if (live) ((f4*)(a.gq + dg * DVS_TILE))[t * 64 + L.lane] = dq;
             }
-            // row statistics (lse, delta) of query i move from lanes r = i to the S-orientation registers i = 4g+reg
-            // through the wave's scratch tile: one b128 read per head and quantity
+            // row statistics (lse, delta) move from lanes r = i to the S-orientation registers i = 4g+reg
             if (L.g == 0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    scr[u * 32 + L.r] = lse[u];
-                    scr[u * 32 + 16 + L.r] = delta[u];
+                for (int u = 0; u < 2; ++u) {
+                    st[u * 32 + L.r] = lse[u];
+                    st[u * 32 + 16 + L.r] = delta[u];
                 }
             }
             dvs_wave_sync();
             // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) --------------------------------------------
             {
-                f4 s2[4], dp[4];
+                f4 s2[2] = {f4_zero(), f4_zero()}, dp[2] = {f4_zero(), f4_zero()};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) s2[u] = dp[u] = f4_zero();
+                for (int kk = 0; kk < 2; ++kk) {
+                    s2[0] = dvs_mfma(q[t][kk], k[t][kk], s2[0]);
+                    s2[1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[1]);
+                    dp[0] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[0]);
+                    dp[1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[1]);
+                }
+                f4 ds[2], pd[2];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 2 * half + tt;
-                        s2[2 * tt] = dvs_mfma(q[t][kk], k[t][kk], s2[2 * tt]);
-                        s2[2 * tt + 1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[2 * tt + 1]);
-                        dp[2 * tt] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[2 * tt]);
-                        dp[2 * tt + 1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[2 * tt + 1]);
-                    }
-                f4 ds[4], pd[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f4 lse_i = *(const f4*)(scr + u * 32 + 4 * L.g);
-                    const f4 del_i = *(const f4*)(scr + u * 32 + 16 + 4 * L.g);
-                    const f4 mk = mask_S(kprob, 4 * half + u, D, L);
+                for (int u = 0; u < 2; ++u) {
+                    const f4 lse_i = *(const f4*)(st + u * 32 + 4 * L.g);
+                    const f4 del_i = *(const f4*)(st + u * 32 + 16 + 4 * L.g);
+                    const f4 mk = mask_S(kprob, 2 * t + u, D, L);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const bool oki = (al4[reg] >> L.r) & 1u;
@@ -284,44 +267,42 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
                     }
                 }
                 dvs_wave_sync();
-                // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register)
+                // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register), stored at once
+                f4 ka = f4_zero(), kb = f4_zero(), va = f4_zero(), vb = f4_zero();
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int t = 2 * half + tt;
-                    f4 ka = f4_zero(), kb = f4_zero(), va = f4_zero(), vb = f4_zero();
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        ka = dvs_mfma(qN[t][kk], ds[2 * tt][kk], ka);
-                        kb = dvs_mfma(qN[t][kk], ds[2 * tt + 1][kk], kb);
-                        va = dvs_mfma(dON[t][kk], pd[2 * tt][kk], va);
-                        vb = dvs_mfma(dON[t][kk], pd[2 * tt + 1][kk], vb);
-                    }
-                    dk[t] = f4{ka[0], ka[1], kb[2], kb[3]};
-                    dv[t] = f4{va[0], va[1], vb[2], vb[3]};
+                for (int kk = 0; kk < 4; ++kk) {
+                    ka = dvs_mfma(qN[t][kk], ds[0][kk], ka);
+                    kb = dvs_mfma(qN[t][kk], ds[1][kk], kb);
+                    va = dvs_mfma(dON[t][kk], pd[0][kk], va);
+                    vb = dvs_mfma(dON[t][kk], pd[1][kk], vb);
+                }
+                if (live) {
+                    ((f4*)(a.gk + dg * DVS_TILE))[t * 64 + L.lane] = f4{ka[0], ka[1], kb[2], kb[3]};
+                    ((f4*)(a.gv + dg * DVS_TILE))[t * 64 + L.lane] = f4{va[0], va[1], vb[2], vb[3]};
                 }
             }
             DVS_SCHED_FENCE();
         }
-        dvs_outer_acc<4, 4>(dWo, dyN, oN);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dq[t] *= scale;
-        dvs_store_tile(a.gq, dag, dq, L);
-        dvs_store_tile(a.gk, dag, dk, L);
-        dvs_store_tile(a.gv, dag, dv, L);
+        // ---- dWo += dy^T O over the group's DAGs ------------------------------------------------------------------
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aWo, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        dvs_group_barrier(G, L);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* rW = (float*)smem;
-    float* rv = rW + DVS_RED_MAT;
-    dvs_stage_dw<4, 4>(rW, dWo, L);
-    dvs_stage_vec<4>(rv, dbo, rv + DVS_RED_VEC + L.wave * DVS_SCR, L);
+    dvs_coop_store((float*)smem, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
+    float* red = (float*)smem;
+    red[L.wave * 64 + L.lane] = vbo;
     __syncthreads();
-    dvs_flush_dw<4, 4>(rW, slab + a.o_out_w, L, 64, 64, 64, false, true);   // columns back to parameter order
-    dvs_flush_vec<4>(rv, slab + a.o_out_b, L);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[w * 64 + threadIdx.x];
+        slab[a.o_out_b + threadIdx.x] = s;
+    }
 }
 
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = attnb_lds_floats(4) * 4;
+    const size_t lds = attnb_lds_floats() * 4;
     DVS_SET_LDS(k_attn_bwd, lds);
-    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(512), lds, st, a);
 }

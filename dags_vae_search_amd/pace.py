@@ -268,15 +268,16 @@ class PaceVaeV3(nn.Module):
                                      self.num_heads, self._graph_label_key, self._graph_label_input,
                                      self._graph_label_output, self._graph_label_start, fixed_memory_len, device)
 
-    def _pack(self, features):
+    def _pack(self, features, check: Optional[bool] = None):
         eng = self._eng()
         dev = self.flat_params.device
+        check = self.nan_check if check is None else check
         if isinstance(features, CompactBatch):       # device-side front-end (records.py): no dense features at all
-            eng.build_records(features.labels.to(dev), features.preds.to(dev), check=self.nan_check)
+            eng.build_records(features.labels.to(dev), features.preds.to(dev), check=check)
             return len(features)
         f = {k: features[k].to(dev) for k in ("vertex_label_features", "vertex_position_features",
                                               "adjacency_matrices", "target_masks")}   # pace.py:1981-1984
-        eng.pack(f, check=self.nan_check)
+        eng.pack(f, check=check)
         return f["vertex_label_features"].shape[0]
 
     def _shape(self, batch: int, beta: float):
@@ -325,12 +326,12 @@ class PaceVaeV3(nn.Module):
 
     # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
-                      packed: bool = False) -> torch.Tensor:
+                      packed: bool = False, defer_check: bool = False) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag]; nothing is synchronised."""
         eng = self._eng()
         if not packed:
-            self._pack(features)
+            self._pack(features, check=False if defer_check else None)
         B = eng._ws_batch
         shape = self._shape(B, beta)
         losses = torch.zeros(4, dtype=torch.float32, device=self.flat_params.device)

@@ -45,12 +45,14 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
     if isinstance(optimizer, FusedAdam):
         if optimizer._model is None:
             optimizer.attach(model)
-        losses = model.loss_and_grad(batch)
+        losses = model.loss_and_grad(batch, defer_check=True)     # feature validation is read with the losses below
         if group is not None:
             from .dist import allreduce_gradients
             allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
         optimizer.step(max_grad_norm=max_grad_norm)
-        host = losses.tolist()                                                      # the step's only host sync
+        host = torch.cat([losses, model._engine._status.float()]).tolist()          # the step's only host sync
+        if host[4] != 0.0:
+            raise ValueError(f"batch violates the feature invariants (status bits {int(host[4]):#x})")
         if host[3] != 0.0:
             raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
         return host[0], losses[1], losses[2]

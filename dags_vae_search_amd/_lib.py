@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdvs_hip.so"
 
 D_MODEL, HEADS, LAYERS, LATENT, FC_HIDDEN, EMB = 64, 8, 3, 32, 32, 32
-MAX_TOKENS = 16
-RECORD_BYTES = 96
+MAX_TOKENS = 48           # 16 on the one-tile path (a wavefront owns a DAG); up to 48 on the tiled wide path
+TILE_TOKENS = 16
+RECORD_BYTES = 96         # one-tile path; record_bytes(lib, shape) gives the size that applies
 
 
 class DvsShape(Structure):
@@ -40,6 +41,8 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_param_table.argtypes = [P(DvsShape), P(DvsParamEntry), c_int]
     lib.dvs_workspace_bytes.restype = c_size_t
     lib.dvs_workspace_bytes.argtypes = [P(DvsShape)]
+    lib.dvs_record_bytes.restype = c_size_t
+    lib.dvs_record_bytes.argtypes = [P(DvsShape)]
     lib.dvs_pack_features.restype = c_int
     lib.dvs_pack_features.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_build_records.restype = c_int
@@ -64,7 +67,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
 
 
@@ -112,6 +115,18 @@ def make_shape(batch: int, n_tokens: int, n_classes: int, training: bool = False
                beta: float = 0.005, eps_scale: float = 0.01, dag_offset: int = 0, seed: int = 0) -> DvsShape:
     return DvsShape(int(batch), int(n_tokens), int(n_classes), 1 if training else 0, float(dropout), float(beta),
                     float(eps_scale), int(dag_offset) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+def record_bytes(lib, shape: DvsShape) -> int:
+    n = int(lib.dvs_record_bytes(ctypes.byref(shape)))
+    if n == 0:
+        check(lib, 1, "dvs_record_bytes")
+    return n
+
+
+def is_wide(n_tokens: int, n_classes: int) -> bool:
+    """Shapes beyond one 16-token / 16-class tile take the workgroup-per-DAG kernels (csrc/dvs_wide.h)."""
+    return n_tokens > TILE_TOKENS or n_classes > 16
 
 
 def param_table(lib, shape: DvsShape):

@@ -6,6 +6,7 @@
 
 #include "dvs_kernels.h"
 #include "dvs_backward.h"
+#include "dvs_wide.h"
 
 static thread_local char g_err[256] = "";
 
@@ -178,7 +179,7 @@ DvsLayout dvs_make_layout(int N, int C, dvs_param_entry* table, int cap, int* co
     return l;
 }
 
-DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab) {
+DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab) {
     DvsWorkspace w;
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -186,10 +187,10 @@ DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab) {
         off += (n + 63) & ~(size_t)63;
         return o;
     };
-    const size_t tile = (size_t)B * 1024;
+    const size_t tile = (size_t)B * NT * 1024;
     for (int s = 0; s < DVS_NSLOTS; ++s) {
         w.act[s] = take(tile);
-        w.stats[s] = take((size_t)B * 32);
+        w.stats[s] = take((size_t)B * NT * 32);
     }
     w.enc_out = take(tile);
     w.mu = take((size_t)B * 32);
@@ -217,16 +218,22 @@ DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab) {
 static int check_shape(const dvs_shape* s) {
     if (!s) return fail(1, "dvs: null shape");
     if (s->batch <= 0) return fail(2, "dvs: batch must be > 0");
-    if (s->n_tokens < 4 || s->n_tokens > DVS_MAXTOK)
-        return fail(3, "dvs: n_tokens (= max_num_vertices + 3) must be in [4, 16] in this build");
-    if (s->n_classes < 4 || s->n_classes > 16)
-        return fail(4, "dvs: n_classes (= vertex_label_cardinality + 3) must be in [4, 16] in this build");
+    if (s->n_tokens < 4 || s->n_tokens > DVS_WTOK)
+        return fail(3, "dvs: n_tokens (= max_num_vertices + 3) must be in [4, 48] in this build");
+    if (s->n_classes < 4 || s->n_classes > DVS_WTOK)
+        return fail(4, "dvs: n_classes (= vertex_label_cardinality + 3) must be in [4, 48] in this build");
     if (!(s->dropout >= 0.f && s->dropout < 1.f)) return fail(5, "dvs: dropout must be in [0, 1)");
     return 0;
 }
 
+// One-tile path: a wave owns a whole DAG (N, C <= 16).  Wide path: NT tiles of 16 tokens per DAG, cross-token kernels
+// of dvs_wide.h (also taken when only the class count exceeds one tile).
+static bool is_wide(const dvs_shape* s) { return s->n_tokens > DVS_MAXTOK || s->n_classes > 16; }
+static int tiles_of(const dvs_shape* s) { return (s->n_tokens + 15) / 16; }
+
 static DvsDims make_dims(const dvs_shape* s) {
     DvsDims d;
+    d.NT = tiles_of(s);
     d.B = s->batch;
     d.N = s->n_tokens;
     d.C = s->n_classes;
@@ -243,9 +250,9 @@ static DvsDims make_dims(const dvs_shape* s) {
     return d;
 }
 
-static int grid_for(int B) {   // forward kernels: 8 waves (512 threads) per workgroup, one DAG per wave at a time
+static int grid_for(int units, int per_wg = 8) {   // persistent forward kernels: `per_wg` units (tiles / DAGs) per pass
     const int cus = dvs_device_cus();
-    const int want = (B + 7) / 8;
+    const int want = (units + per_wg - 1) / per_wg;
     const int cap = cus > 0 ? cus : 256;
     return want < cap ? want : cap;
 }
@@ -270,7 +277,12 @@ extern "C" int dvs_param_table(const dvs_shape* s, dvs_param_entry* out, int cap
 extern "C" size_t dvs_workspace_bytes(const dvs_shape* s) {
     if (check_shape(s)) return 0;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
-    return dvs_make_workspace(s->batch, P, dvs_num_slabs()).total_floats * sizeof(float);
+    return dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs()).total_floats * sizeof(float);
+}
+
+extern "C" size_t dvs_record_bytes(const dvs_shape* s) {
+    if (check_shape(s)) return 0;
+    return is_wide(s) ? sizeof(DvsRecordW) : sizeof(DvsRecord);
 }
 
 extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
@@ -289,20 +301,33 @@ extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, 
     a.tmask = target_masks;
     a.rec = (DvsRecord*)records;
     a.status = status;
-    dvs_launch_pack(a, (dvs_stream_t)stream);
+    if (is_wide(s)) dvs_launch_pack_w(a, (dvs_stream_t)stream);
+    else dvs_launch_pack(a, (dvs_stream_t)stream);
     return 0;
 }
 
-extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const uint16_t* preds, void* records,
+extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* preds, void* records,
                                  int32_t* status, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!labels || !preds || !records || !status) return fail(10, "dvs_build_records: null pointer");
+    if (is_wide(s)) {
+        BuildWArgs a;
+        a.B = s->batch;
+        a.N = s->n_tokens;
+        a.C = s->n_classes;
+        a.labels = labels;
+        a.preds = (const uint64_t*)preds;
+        a.rec = (DvsRecordW*)records;
+        a.status = status;
+        dvs_launch_build_records_w(a, (dvs_stream_t)stream);
+        return 0;
+    }
     BuildArgs a;
     a.B = s->batch;
     a.N = s->n_tokens;
     a.C = s->n_classes;
     a.labels = labels;
-    a.preds = preds;
+    a.preds = (const uint16_t*)preds;
     a.rec = (DvsRecord*)records;
     a.status = status;
     dvs_launch_build_records(a, (dvs_stream_t)stream);
@@ -316,8 +341,32 @@ static inline int slot_dec(int layer, int sub) { return 8 + 3 * layer + sub; }  
 static inline int site_enc(int layer, int k) { return 4 + 4 * layer + k; }
 static inline int site_dec(int layer, int k) { return 16 + 6 * layer + k; }
 
+// launch grids of the forward kernels
+struct FwdGrids {
+    bool wide;
+    int tiles8;     // 8-wave tile-parallel kernels (k_ffn_fwd; one-tile k_attn_fwd / k_embed_fwd / k_loss_fwd)
+    int tiles4;     // 4-wave tile-parallel kernels (k_embed_fwd_w)
+    int dags;       // workgroup-per-DAG kernels of the wide path
+};
+static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
+    FwdGrids g;
+    g.wide = wide;
+    g.tiles8 = grid_for(d.B * d.NT, 8);
+    g.tiles4 = grid_for(d.B * d.NT, 4);
+    g.dags = grid_for(d.B, 1);
+    return g;
+}
+static void launch_embed_fwd(const EmbedArgs& e, const FwdGrids& g, dvs_stream_t st) {
+    if (g.wide) dvs_launch_embed_fwd_w(e, g.tiles4, st);
+    else dvs_launch_embed_fwd(e, g.tiles8, st);
+}
+static void launch_attn_fwd(const AttnArgs& a, const FwdGrids& g, dvs_stream_t st) {
+    if (g.wide) dvs_launch_attn_fwd_w(a, g.dags, st);
+    else dvs_launch_attn_fwd(a, g.tiles8, st);
+}
+
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
-                            const float* P, float* ws, int grid, dvs_stream_t st) {
+                            const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st) {
     EmbedArgs e;
     memset(&e, 0, sizeof(e));
     e.dims = d;
@@ -328,7 +377,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
     e.lab_b = P + L.lab_b;
     e.out = ws + W.act[0];
     e.site = 0;
-    dvs_launch_embed_fwd(e, grid, st);
+    launch_embed_fwd(e, grid, st);
     DvsLN ln = {nullptr, nullptr, nullptr};
     int prev = 0;
     for (int i = 0; i < DVS_LAYERS; ++i) {
@@ -348,7 +397,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.out_stats = ws + W.stats[sa];
         a.site_prob = site_enc(i, 0);
         a.site_post = site_enc(i, 1);
-        dvs_launch_attn_fwd(a, grid, st);
+        launch_attn_fwd(a, grid, st);
         FfnArgs f;
         memset(&f, 0, sizeof(f));
         f.dims = d;
@@ -368,7 +417,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
             f.ng = P + L.enc[i].n2.w;
             f.nb = P + L.enc[i].n2.b;
         }
-        dvs_launch_ffn_fwd(f, grid, st);
+        dvs_launch_ffn_fwd(f, grid.tiles8, st);
         ln = DvsLN{ws + W.stats[sf], P + L.enc[i].n2.w, P + L.enc[i].n2.b};
         prev = sf;
     }
@@ -423,11 +472,11 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
     if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, L.total, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
     float* ws = (float*)workspace;
     const DvsRecord* rec = (const DvsRecord*)records;
     dvs_stream_t st = (dvs_stream_t)stream;
-    const int grid = grid_for(d.B);
+    const FwdGrids grid = fwd_grids(d, is_wide(s));
 
     encoder_forward(d, L, W, rec, params, ws, grid, st);
     dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
@@ -446,7 +495,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
         e.lab_b = params + L.lab_b;
         e.out = ws + W.act[7];
         e.site = 2;
-        dvs_launch_embed_fwd(e, grid, st);
+        launch_embed_fwd(e, grid, st);
         dec_in = 7;
     }
     DvsLN ln = {nullptr, nullptr, nullptr};
@@ -468,7 +517,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
         a.out_stats = ws + W.stats[s0];
         a.site_prob = site_dec(i, 0);
         a.site_post = site_dec(i, 1);
-        dvs_launch_attn_fwd(a, grid, st);
+        launch_attn_fwd(a, grid, st);
 
         AttnArgs c;
         memset(&c, 0, sizeof(c));
@@ -486,7 +535,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
         c.out_stats = ws + W.stats[s1];
         c.site_prob = site_dec(i, 2);
         c.site_post = site_dec(i, 3);
-        dvs_launch_attn_fwd(c, grid, st);
+        launch_attn_fwd(c, grid, st);
 
         FfnArgs f;
         memset(&f, 0, sizeof(f));
@@ -502,11 +551,12 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
         f.out_stats = ws + W.stats[s2];
         f.site_hidden = site_dec(i, 4);
         f.site_post = site_dec(i, 5);
-        dvs_launch_ffn_fwd(f, grid, st);
+        dvs_launch_ffn_fwd(f, grid.tiles8, st);
         ln = DvsLN{ws + W.stats[s2], params + pl.n3.w, params + pl.n3.b};
         prev = s2;
     }
-    dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid, st);
+    if (grid.wide) dvs_launch_loss_fwd_w(dvs_loss_args(d, L, W, rec, params, ws), grid.dags, st);
+    else dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.tiles8, st);
     FinalizeArgs fa;
     fa.B = d.B;
     fa.beta = d.beta;
@@ -530,10 +580,10 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* 
     if (!records || !params || !workspace || !mu || !logvar) return fail(10, "dvs_encode: null pointer");
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, L.total, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
-    encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, grid_for(d.B), st);
+    encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st);
     LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
     la.dims.training = 0;
     dvs_launch_latent_fwd(la, st);
@@ -551,7 +601,7 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* 
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
     if (int e = check_shape(s)) return e;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
-    const DvsWorkspace W = dvs_make_workspace(s->batch, P, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs());
     const float* ws = (const float*)workspace;
     const float* src = nullptr;
     if (slot >= 0 && slot < DVS_NSLOTS) src = ws + W.act[slot];
@@ -562,7 +612,7 @@ extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, i
     else if (slot == 104) src = ws + W.gmem;
     else if (slot == 105) src = ws + W.genc;
     else return fail(11, "dvs_debug_activation: bad slot");
-    dvs_launch_unfrag(src, out, s->batch, (dvs_stream_t)stream);
+    dvs_launch_unfrag(src, out, s->batch * tiles_of(s), (dvs_stream_t)stream);
     return 0;
 }
 

@@ -365,13 +365,14 @@ struct DvsDrop {
     float scale;         // 1 / (1 - thr16/65536)
     int on;              // training && p > 0
 };
-// element index of (token, feature) within a [16][64] site: tok*64 + f; a lane's f4 covers features 16t+4g..+3
+// element index of (token, feature) within a [tokens][64] site: tok*64 + f; a lane's f4 covers features 16t+4g..+3
 // -> pair indices (tok*64 + 16t + 4g)/2 and +1.
-__device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[4], uint32_t key, const DvsDrop& D, const Lane& L) {
+// tok0: token index of the tile's row 0 (0 on the one-tile path; 16 * tile-in-DAG on the wide path)
+__device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[4], uint32_t key, const DvsDrop& D, const Lane& L, int tok0 = 0) {
     if (!D.on) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const uint32_t p0 = (uint32_t)(L.r * 64 + 16 * t + 4 * L.g) >> 1;
+        const uint32_t p0 = (uint32_t)((tok0 + L.r) * 64 + 16 * t + 4 * L.g) >> 1;
         const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
         x[t][0] = ((h0 & 0xFFFFu) >= D.thr16) ? x[t][0] * D.scale : 0.f;
         x[t][1] = ((h0 >> 16) >= D.thr16) ? x[t][1] * D.scale : 0.f;

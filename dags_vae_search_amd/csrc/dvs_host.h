@@ -10,7 +10,8 @@ constexpr int DVS_HEADS = 8;
 constexpr int DVS_LATENT = 32;
 constexpr int DVS_FCH = 32;   // fc_hidden
 constexpr int DVS_EMB = 32;   // vertices_embedding_size
-constexpr int DVS_MAXTOK = 16;
+constexpr int DVS_MAXTOK = 16;   // tokens of one tile (narrow path: whole DAG)
+constexpr int DVS_WTOK = 48;     // widest DAG of the tiled ("wide") path: 3 tiles of 16 tokens (alarm n = 37 -> N = 40)
 constexpr int DVS_FC_PARTS = 16; // batch parts of the fc1/fc2/fc3 weight-gradient GEMMs
 constexpr int DVS_NSLOTS = 17;   // saved activation slots: 0 enc-embed, 1..6 enc sublayers, 7 dec-embed, 8..16 dec sublayers
 
@@ -37,6 +38,7 @@ struct DvsDropH {   // host mirror of DvsDrop (dvs_device.h)
 
 struct DvsDims {
     int B, N, C, training;
+    int NT;                     // 16-token tiles per DAG: 1 (N <= 16, one wave owns a DAG) or ceil(N/16) (wide path)
     DvsDropH drop;
     uint32_t seed_lo, seed_hi, dag_offset;
     float beta, eps_scale;
@@ -45,7 +47,7 @@ struct DvsDims {
 
 // Workspace layout (float offsets unless noted); every region is 256-byte aligned.
 struct DvsWorkspace {
-    size_t act[DVS_NSLOTS];     // [B][1024] frag-order pre-LayerNorm sums (slot 0/7: embedding outputs)
+    size_t act[DVS_NSLOTS];     // [B*NT][1024] frag-order pre-LayerNorm sums (slot 0/7: embedding outputs)
     size_t stats[DVS_NSLOTS];   // [B][32]: mean[16], rstd[16] of the slot's LayerNorm
     size_t enc_out;             // [B][1024] LayerNorm'ed encoder output (input of fc1/fc2)
     size_t mu, logvar, z, epsv; // [B][32]
@@ -62,4 +64,4 @@ struct DvsWorkspace {
     int nslab;
 };
 
-DvsWorkspace dvs_make_workspace(int B, int64_t P, int nslab);
+DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab);

@@ -10,7 +10,7 @@ typedef void* dvs_stream_t;
 #endif
 
 struct DvsLN {                   // LayerNorm applied in a consumer's prologue: x = (pre - mean) * rstd * g + b
-    const float* stats;          // [B][32] (mean[16], rstd[16]); null = identity (embedding output)
+    const float* stats;          // [tiles][32] (mean[16], rstd[16]); null = identity (embedding output)
     const float* g;
     const float* b;
 };
@@ -128,6 +128,28 @@ void dvs_prof_end(dvs_stream_t st);
 #else
 #define DVS_SET_LDS(kernel, bytes) ((void)0)
 #endif
+
+// ---- tiles ------------------------------------------------------------------------------------------------------
+// Activation buffers hold B*NT frag-order tiles; tile `tile` is rows tok0 .. tok0+15 of DAG `dag`, of which the first
+// Nl are real tokens.  NT == 1 (N <= 16): tile == dag.  The token-local kernels (FFN, projection backward) loop over
+// tiles and are oblivious to which DAG a tile belongs to except for the dropout key and element index.
+struct DvsTile {
+    int dag, tok0, Nl;
+};
+__device__ __forceinline__ DvsTile dvs_tile_of(int tile, const DvsDims& d) {
+    DvsTile t;
+    if (d.NT == 1) {
+        t.dag = tile;
+        t.tok0 = 0;
+        t.Nl = d.N;
+    } else {
+        t.dag = tile / d.NT;
+        t.tok0 = 16 * (tile - t.dag * d.NT);
+        const int nl = d.N - t.tok0;
+        t.Nl = nl < 0 ? 0 : (nl > 16 ? 16 : nl);
+    }
+    return t;
+}
 
 __device__ __forceinline__ DvsDrop dvs_drop_of(const DvsDims& d) {
     DvsDrop D;

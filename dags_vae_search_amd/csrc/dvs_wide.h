@@ -1,0 +1,170 @@
+// "Wide" path: DAGs of 17..48 tokens (alarm-size, n = 37 -> N = 40; BASELINE config 5).
+//
+// A DAG is NT = ceil(N/16) consecutive frag-order tiles of 16 tokens.  Everything token-local (the 64x64 linears,
+// LayerNorm, dropout, residuals: k_ffn_*, k_proj_bwd, the latent GEMMs) runs on the SAME kernels as the one-tile path,
+// looping over tiles (dvs_tile_of).  The three cross-token operations get workgroup-per-DAG kernels here: wave w of a
+// 4-wave workgroup owns tile w (its MFMA chains are those of the one-tile kernels), and the tiles of a DAG meet in LDS:
+//   * positional embedding: every token gathers the W1 rows of its parents' positions from an LDS image of W1
+//     (pace.py:214 adj^T @ pos_onehot) — the parent-hidden gather BASELINE config 5 stresses;
+//   * attention core: q, k, v of all tiles are parked row-major in LDS, one thread per (token, head) walks the token's
+//     ancestor bit-row (scores, softmax, dropout, P'V on the VALU: 8-wide heads are below MFMA tile size);
+//   * edge-pair head: V = Wb h + b1 of all tokens parked in LDS, lane (token i) walks j < i.
+// Workgroups are persistent (grid = #CU) so that weight gradients keep the slab scheme of dvs_backward.h.
+#pragma once
+#include "dvs_backward.h"
+
+constexpr int DVS_WNT = 3;                       // tiles per DAG at most
+constexpr int DVS_WSCR = DVS_WTOK * DVS_LD;      // floats of a [48][DVS_LD] row-major DAG tile set in LDS
+
+struct DvsRecordW {              // compact per-DAG record of the wide path (864 bytes)
+    uint8_t label[DVS_WTOK];
+    uint8_t pos[DVS_WTOK];
+    uint64_t parents[DVS_WTOK];  // bit j: edge j -> i
+    uint64_t allowed[DVS_WTOK];  // bit j: token i may attend token j
+};
+
+__device__ __forceinline__ int dvs_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+
+// rows of real tokens in tile `w` of an N-token DAG
+__device__ __forceinline__ int dvs_rows_of(int N, int w) {
+    const int nl = N - 16 * w;
+    return nl < 0 ? 0 : (nl > 16 ? 16 : nl);
+}
+
+// T-layout / N-layout register tiles of rows tok0.. of a row-major [tokens][DVS_LD] LDS buffer
+__device__ __forceinline__ void dvs_lds_T(f4 (&x)[4], const float* buf, int tok0, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = *(const f4*)(buf + (tok0 + L.r) * DVS_LD + 16 * t + 4 * L.g);
+}
+__device__ __forceinline__ void dvs_lds_N(f4 (&x)[4], const float* buf, int tok0, const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float* p = buf + (tok0 + 4 * L.g) * DVS_LD + 16 * t + L.r;
+        x[t] = f4{p[0], p[DVS_LD], p[2 * DVS_LD], p[3 * DVS_LD]};
+    }
+}
+
+__device__ __forceinline__ float dvs_dot8(const f4& a0, const f4& a1, const float* p) {
+    const f4 b0 = *(const f4*)p, b1 = *(const f4*)(p + 4);
+    float s = a0[0] * b0[0];
+    s = fmaf(a0[1], b0[1], s);
+    s = fmaf(a0[2], b0[2], s);
+    s = fmaf(a0[3], b0[3], s);
+    s = fmaf(a1[0], b1[0], s);
+    s = fmaf(a1[1], b1[1], s);
+    s = fmaf(a1[2], b1[2], s);
+    s = fmaf(a1[3], b1[3], s);
+    return s;
+}
+
+// ---- LDS images shared by the forward and backward kernels ---------------------------------------------------------
+constexpr int EMBW_LABLD = DVS_WTOK;             // labw image [32][48]
+struct EmbWLds {
+    float *W1, *W2, *labw, *labb;
+};
+__device__ __forceinline__ EmbWLds embw_lds(char* smem) {
+    EmbWLds l;
+    l.W1 = (float*)smem;                         // [2*48][LD]
+    l.W2 = l.W1 + 2 * DVS_WTOK * DVS_LD;         // [64][36]
+    l.labw = l.W2 + 64 * EMB_LDW2;               // [32][48]
+    l.labb = l.labw + 32 * EMBW_LABLD;
+    return l;
+}
+constexpr size_t EMBW_FLOATS = 2 * DVS_WTOK * DVS_LD + 64 * EMB_LDW2 + 32 * EMBW_LABLD + 32;
+
+__device__ __forceinline__ void embw_stage(const EmbWLds& l, const EmbedArgs& a) {
+    const int N = a.dims.N, C = a.dims.C;
+    dvs_stage_matrix(l.W1, DVS_LD, a.W1, 64, 2 * N, 64);
+    dvs_stage_matrix(l.W2, EMB_LDW2, a.W2, 32, 64, 32);
+    for (int i = threadIdx.x; i < 32 * EMBW_LABLD; i += blockDim.x) {
+        const int f = i / EMBW_LABLD, c = i - f * EMBW_LABLD;
+        l.labw[i] = c < C ? a.lab_w[f * C + c] : 0.f;
+    }
+    dvs_stage_vector(l.labb, a.lab_b, 32);
+}
+
+// hidden of the positional encoder for token tok0 + r (T-layout), post-ReLU, before dropout; zero for padding rows
+__device__ __forceinline__ void embw_hidden(f4 (&e1)[4], const float* W1, const DvsRecordW* rec, int N, int tok0, int Nl,
+                                            const Lane& L) {
+    const bool valid = L.r < Nl;
+    const int i = valid ? tok0 + L.r : 0;
+    const float* row = W1 + rec->pos[i] * DVS_LD + 4 * L.g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) e1[t] = valid ? *(const f4*)(row + 16 * t) : f4_zero();
+    uint64_t pm = valid ? rec->parents[i] : 0ull;
+    while (pm) {
+        const int j = dvs_ctz64(pm);
+        pm &= pm - 1;
+        const float* prow = W1 + (N + rec->pos[j]) * DVS_LD + 4 * L.g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e1[t] += *(const f4*)(prow + 16 * t);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) e1[t][kk] = fmaxf(e1[t][kk], 0.f);
+}
+
+constexpr int LOSSW_LDN2 = 36;
+struct LossWLds {
+    float *Wn1, *Wn2, *Wa, *Wb, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *V, *U, *dlm, *part, *scr;
+};
+__device__ __forceinline__ LossWLds lossw_lds(char* smem) {
+    LossWLds l;
+    l.Wn1 = (float*)smem;                       // [32][LD]
+    l.Wn2 = l.Wn1 + 32 * DVS_LD;                // [48][36], rows >= C zero
+    l.Wa = l.Wn2 + DVS_WTOK * LOSSW_LDN2;
+    l.Wb = l.Wa + 64 * DVS_LD;
+    l.bn1 = l.Wb + 64 * DVS_LD;                 // 32
+    l.bn2 = l.bn1 + 32;                         // 48
+    l.be1 = l.bn2 + DVS_WTOK;                   // 64
+    l.w2 = l.be1 + 64;                          // 64
+    l.b2 = l.w2 + 64;                           // 16
+    l.lg = l.b2 + 16;
+    l.lb = l.lg + 64;
+    l.V = l.lb + 64;                            // [48][LD] shared
+    l.U = l.V + DVS_WSCR;                       // [48][LD] shared (backward)
+    l.dlm = l.U + DVS_WSCR;                     // [48][49] d logit matrix (backward)
+    l.part = l.dlm + DVS_WTOK * (DVS_WTOK + 1); // 16
+    l.scr = l.part + 16;                        // 4 per-wave transpose tiles (backward)
+    return l;
+}
+static inline size_t dvs_lossw_lds_floats() {
+    return 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128 + 2 * (size_t)DVS_WSCR +
+           DVS_WTOK * (DVS_WTOK + 1) + 16 + 4 * (size_t)DVS_SCR;
+}
+__device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a) {
+    const int C = a.dims.C;
+    dvs_stage_matrix(l.Wn1, DVS_LD, a.node0_w, 64, 32, 64);
+    for (int i = threadIdx.x; i < DVS_WTOK * 32; i += blockDim.x) {
+        const int c = i >> 5, k = i & 31;
+        l.Wn2[c * LOSSW_LDN2 + k] = c < C ? a.node2_w[c * 32 + k] : 0.f;
+    }
+    dvs_stage_matrix(l.Wa, DVS_LD, a.edge0_w, 128, 64, 64);
+    dvs_stage_matrix(l.Wb, DVS_LD, a.edge0_w + 64, 128, 64, 64);
+    dvs_stage_vector(l.bn1, a.node0_b, 32);
+    for (int i = threadIdx.x; i < DVS_WTOK; i += blockDim.x) l.bn2[i] = i < C ? a.node2_b[i] : 0.f;
+    dvs_stage_vector(l.be1, a.edge0_b, 64);
+    dvs_stage_vector(l.w2, a.edge2_w, 64);
+    if (threadIdx.x == 0) l.b2[0] = a.edge2_b[0];
+    dvs_stage_vector(l.lg, a.ln.g, 64);
+    dvs_stage_vector(l.lb, a.ln.b, 64);
+    for (int i = threadIdx.x; i < 2 * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
+}
+
+struct BuildWArgs {
+    int B, N, C;
+    const uint8_t* labels;       // [B][n]
+    const uint64_t* preds;       // [B][n]
+    DvsRecordW* rec;
+    int* status;
+};
+
+void dvs_launch_pack_w(const PackArgs& a, dvs_stream_t st);
+void dvs_launch_build_records_w(const BuildWArgs& a, dvs_stream_t st);
+void dvs_launch_embed_fwd_w(const EmbedArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_attn_fwd_w(const AttnArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_loss_fwd_w(const LossArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_embed_bwd_w(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
+void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_loss_bwd_w(const LossArgs& a, int grid, dvs_stream_t st);

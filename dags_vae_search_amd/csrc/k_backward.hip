@@ -45,17 +45,19 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
-    const int N = a.dims.N, B = a.dims.B;
+    const int B = a.dims.B * a.dims.NT;                    // tiles (dvs_tile_of): the sublayer is token-local
     float* sA = l.slots + L.wave * 2 * DVS_SCR;
     float* sB = sA + DVS_SCR;
     DvsGroup G = {gcount + (L.wave >> 2), 0};
     f4 aW1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, aW2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     float vb1 = 0.f, vb2 = 0.f, vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;    // lane = feature
     for (int base = blockIdx.x * 8; base < B; base += gridDim.x * 8) {
-        const int dag = base + L.wave;
+        const int dag = base + L.wave;                     // tile index
         const bool live = dag < B;
         const size_t dg = live ? dag : 0;
-        const int Nl = live ? N : 0;                       // a wave without a DAG carries all-zero tiles
+        const DvsTile T = dvs_tile_of((int)dg, a.dims);
+        const int N = T.Nl;
+        const int Nl = live ? N : 0;                       // a wave without a tile carries all-zero tiles
         f4 x[4], xhat[4], gp[4];
         float rstd;
         dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
             dvs_wave_sync();
             dvs_ln_bwd_core(gp, pxh, prstd, l.og, L);
         }
-        const uint32_t gdag = a.dims.dag_offset + (uint32_t)dg;
+        const uint32_t gdag = a.dims.dag_offset + (uint32_t)T.dag;
         const uint32_t khid = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag);
         const uint32_t kpost = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag);
         // recompute hidden
@@ -86,12 +88,12 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) hd[t][kk] = (live && L.r < N) ? fmaxf(hpre[t][kk], 0.f) : 0.f;
-        dvs_dropout_tile(hd, khid, D, L);
+        dvs_dropout_tile(hd, khid, D, L, T.tok0);
         // dy = d(W2 h + b2) = dropout-mask(post) applied to d pre
         f4 dy[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dy[t] = gp[t];
-        dvs_dropout_tile(dy, kpost, D, L);
+        dvs_dropout_tile(dy, kpost, D, L, T.tok0);
         // ---- dW2 += dy^T hd, db2 += sum dy --------------------------------------------------------------------------
         dvs_park_T(sA, dy, L);
         dvs_park_T(sB, hd, L);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_coop_dw(aW2, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
         dvs_mat_Tt<4, 4>(dh, dy, l.W2, DVS_LD, 0, L);
-        dvs_dropout_tile(dh, khid, D, L);
+        dvs_dropout_tile(dh, khid, D, L, T.tok0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
     if (threadIdx.x < 2) gcount[threadIdx.x] = 0;
     __syncthreads();
     const Lane L = dvs_lane();
-    const int N = a.dims.N, B = a.dims.B;
+    const int B = a.dims.B * a.dims.NT;              // tiles
     float* myA0 = slots + L.wave * 3 * DVS_SCR;
     float* myA1 = myA0 + DVS_SCR;
     float* myB = myA0 + 2 * DVS_SCR;
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
         for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
     }
     for (int base = blockIdx.x * 8; base < B; base += gridDim.x * 8) {
-        const int dag = base + L.wave;
+        const int dag = base + L.wave;               // tile index
         const bool live = dag < B;
         const size_t dg = live ? dag : 0;
-        const int Nl = live ? N : 0;
+        const int Nl = live ? dvs_tile_of((int)dg, a.dims).Nl : 0;
         f4 x[4], xhat[4], dx[4];
         float rstd;
         dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dg, Nl, L);

@@ -380,15 +380,17 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
     const float gkl = a.gcoef[1];
     const int dag = blockIdx.x * 16 + L.r;
     const bool dvalid = dag < B;
-    const int m0 = 16 * L.wave;
+    const int NT = a.dims.NT, mch = 16 * NT;          // chunk m: tile m >> 6, chunk m & 63 of it (k_latent_fwd)
+    const size_t dstride = (size_t)NT * DVS_TILE;
+    const int m0 = mch * L.wave;
     f4 dz[2] = {f4_zero(), f4_zero()};
 #pragma unroll 4
-    for (int mi = 0; mi < 16; ++mi) {
-        const int m = m0 + mi;
-        const int tok = 4 * (m & 3) + L.g;
-        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+    for (int mi = 0; mi < mch; ++mi) {
+        const int m = m0 + mi, mm = m & 63;
+        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
+        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
         const bool tv = tok < N;
-        const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
+        const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
         const float* wp = a.fc3_w + (size_t)((tv ? tok : 0) * 64 + fb) * 32 + L.r;
         f4 wa[2];
 #pragma unroll
@@ -431,11 +433,11 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
     }
     // d enc_out^T[k'][dag] = sum_o Wfc[o][col(k')] dout^T[o][dag]
 #pragma unroll 2
-    for (int mi = 0; mi < 16; ++mi) {
-        const int m = m0 + mi;
-        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-        const int tokD = 4 * (m & 3) + L.g;
-        const int tokA = 4 * (m & 3) + (L.r >> 2);
+    for (int mi = 0; mi < mch; ++mi) {
+        const int m = m0 + mi, mm = m & 63;
+        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
+        const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
+        const int tokA = 16 * (m >> 6) + 4 * (mm & 3) + (L.r >> 2);
         const bool av = tokA < N;
         const size_t colA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
         f4 wa[4];
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
             o0 = dvs_mfma(wa[2][kk], dout[2][kk], o0);
             o1 = dvs_mfma(wa[3][kk], dout[3][kk], o1);
         }
-        if (dvalid) *(f4*)(a.genc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o0 + o1 : f4_zero();
+        if (dvalid) *(f4*)(a.genc + (size_t)dag * dstride + 16 * m + 4 * L.g) = tokD < N ? o0 + o1 : f4_zero();
     }
 }
 
@@ -476,7 +478,9 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
     const int ldw = N * 64;
-    const int mg = blockIdx.x & 15, q = blockIdx.x >> 4;
+    const int nmg = 16 * a.dims.NT;                                // groups of FC_MT column tiles (64 * NT tiles in all)
+    const int mg = blockIdx.x % nmg, q = blockIdx.x / nmg;
+    const size_t dstride = (size_t)a.dims.NT * DVS_TILE;
     const int per_q = (B + DVS_FC_PARTS - 1) / DVS_FC_PARTS;
     const int per_w = (per_q + 3) / 4;
     const int d0 = q * per_q + L.wave * per_w;
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
             for (int t = 0; t < 2; ++t) zb[t] = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
 #pragma unroll
             for (int j = 0; j < FC_MT; ++j) {
-                xb[j] = dv ? a.xenc[dd * DVS_TILE + 16 * (FC_MT * mg + j) + L.r] : 0.f;
-                gm[j] = dv ? a.gmem[dd * DVS_TILE + 16 * (FC_MT * mg + j) + L.r] : 0.f;
+                xb[j] = dv ? a.xenc[dd * dstride + 16 * (FC_MT * mg + j) + L.r] : 0.f;
+                gm[j] = dv ? a.gmem[dd * dstride + 16 * (FC_MT * mg + j) + L.r] : 0.f;
                 bs3[j] += gm[j];
             }
 #pragma unroll
@@ -552,9 +556,10 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
     }
     float* out = a.fcpart + (size_t)q * a.P;
     // tot[t][reg] = dWfc[o = 16t + 4g + reg][k' = 16m + r]
+    const int mm = m & 63;
     {
-        const int tok = 4 * (m & 3) + (L.r >> 2);
-        const int f = 16 * (m >> 4) + 4 * ((m >> 2) & 3) + (L.r & 3);
+        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + (L.r >> 2);
+        const int f = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3) + (L.r & 3);
         if (tok < N) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -571,8 +576,8 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
     }
     // tot[4+t][reg] = dW3[row(k' = 16m + 4g + reg)][o = 16t + r]
     {
-        const int tok = 4 * (m & 3) + L.g;
-        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
+        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
         if (tok < N) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -588,5 +593,5 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
 }
 
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st) {
-    DVS_LAUNCH(k_fc_dw, dim3(16 * DVS_FC_PARTS), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_fc_dw, dim3(16 * a.dims.NT * DVS_FC_PARTS), dim3(256), 0, st, a);
 }

@@ -472,12 +472,13 @@ __global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
-    const int N = a.dims.N;
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    const int ntiles = a.dims.B * a.dims.NT;
+    for (int tile = blockIdx.x * L.nwaves + L.wave; tile < ntiles; tile += gridDim.x * L.nwaves) {
+        const DvsTile T = dvs_tile_of(tile, a.dims);
         f4 x[4], dummy[4];
         float rstd;
-        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
-        const uint32_t gdag = a.dims.dag_offset + dag;
+        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, T.Nl, L);
+        const uint32_t gdag = a.dims.dag_offset + T.dag;
         f4 h[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] = dvs_vecT(l.b1, t, L);
@@ -486,23 +487,23 @@ __global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) h[t][kk] = fmaxf(h[t][kk], 0.f);
-        dvs_dropout_tile(h, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag), D, L);
+        dvs_dropout_tile(h, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag), D, L, T.tok0);
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.b2, t, L);
         dvs_mat_T<4, 4>(y, h, l.W2, DVS_LD, 0, L);
-        dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
-        const bool valid = L.r < N;
+        dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, T.tok0);
+        const bool valid = L.r < T.Nl;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
         float mean, rs;
         dvs_ln_stats(y, mean, rs);
-        dvs_store_tile(a.out_pre, dag, y, L);
+        dvs_store_tile(a.out_pre, tile, y, L);
         if (L.g == 0) {
-            a.out_stats[(size_t)dag * 32 + L.r] = mean;
-            a.out_stats[(size_t)dag * 32 + 16 + L.r] = rs;
+            a.out_stats[(size_t)tile * 32 + L.r] = mean;
+            a.out_stats[(size_t)tile * 32 + 16 + L.r] = rs;
         }
         if (a.out_norm) {
             f4 xn[4];
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) xn[t][kk] = valid ? (y[t][kk] - mean) * rs * g[kk] + b[kk] : 0.f;
             }
-            dvs_store_tile(a.out_norm, dag, xn, L);
+            dvs_store_tile(a.out_norm, tile, xn, L);
         }
     }
 }
@@ -523,7 +524,7 @@ void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(512), lds, st, a);
 }
 
-// frag-order [B][1024] -> natural [B][16][64] (debug / tests)
+// frag-order [tiles][1024] -> natural [tiles][16][64] (= [B][16*NT][64]) (debug / tests)
 __global__ void k_unfrag(const float* frag, float* out, int B) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * 1024) return;

@@ -26,14 +26,17 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
     const int dag = grp * 16 + L.r;
     const bool dvalid = dag < B;
     f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-    const int m0 = 16 * L.wave;
+    // chunk m of the DAG's NT frag-order tiles: tile m >> 6, 16-float chunk mm = m & 63 of that tile
+    const int NT = a.dims.NT, mch = 16 * NT;
+    const size_t dstride = (size_t)NT * DVS_TILE;
+    const int m0 = mch * L.wave;
 #pragma unroll 4
-    for (int mi = 0; mi < 16; ++mi) {
-        const int m = m0 + mi;
-        const int tok = 4 * (m & 3) + L.g;
-        const int f0 = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
+    for (int mi = 0; mi < mch; ++mi) {
+        const int m = m0 + mi, mm = m & 63;
+        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
+        const int f0 = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
         const bool tv = tok < N;
-        const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) : f4_zero();
+        const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
         const int col = (tv ? tok : 0) * 64 + f0;
         f4 wa[4];
 #pragma unroll
@@ -89,11 +92,11 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
     if (L.wave == 0 && L.g == 0 && dvalid && a.dag_loss) a.dag_loss[(size_t)dag * 2 + 1] = kl;
     if (!a.mem) return;
 #pragma unroll 4
-    for (int mi = 0; mi < 16; ++mi) {
-        const int m = m0 + mi;
-        const int fb = 16 * (m >> 4) + 4 * ((m >> 2) & 3);
-        const int tokD = 4 * (m & 3) + L.g;            // token of this lane's 4 result rows
-        const int tokA = 4 * (m & 3) + (L.r >> 2);     // token of this lane's A row
+    for (int mi = 0; mi < mch; ++mi) {
+        const int m = m0 + mi, mm = m & 63;
+        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
+        const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;            // token of this lane's 4 result rows
+        const int tokA = 16 * (m >> 6) + 4 * (mm & 3) + (L.r >> 2);     // token of this lane's A row
         const bool av = tokA < N;
         const size_t rowA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
         f4 o = tokD < N ? *(const f4*)(a.fc3_b + tokD * 64 + fb) : f4_zero();
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(wa[kk], z[t][kk], o);
         }
-        if (dvalid) *(f4*)(a.mem + (size_t)dag * DVS_TILE + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
+        if (dvalid) *(f4*)(a.mem + (size_t)dag * dstride + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
     }
 }
 

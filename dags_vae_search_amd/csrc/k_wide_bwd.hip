@@ -1,0 +1,637 @@
+// Wide path (17..48 tokens per DAG), backward kernels: attention core, loss head, embedding.
+// See dvs_wide.h for the execution model.  Persistent workgroups of 4 waves (grid = number of gradient slabs); wave w
+// owns tile w of the workgroup's current DAG and accumulates weight gradients in MFMA accumulators exactly like the
+// one-tile kernels; the workgroup's waves are added in fixed order through LDS and written to the workgroup's slab.
+#include "dvs_wide.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention-core backward, wide: d(pre) -> d q, d k, d v projections (frag tiles, natural feature order) and dWo, dbo.
+// Nothing but the sublayer input was saved: q, k, v and the probabilities are recomputed.
+//   wave w   : x -> q,k,v parked in LDS; dy = dropout-mask(d pre); dO^T = Wo^T dy parked          | barrier
+//   phase A  : thread (i, h): row statistics (lse, delta), O_i (for dWo), dq_i                     | barrier
+//   phase B  : thread (j, h): walks the queries i that may attend j; dk_j, dv_j in registers       | barrier
+//              dk, dv overwrite the K, V buffers                                                    | barrier
+//   wave w   : stores dq, dk, dv tiles; dWo += dy(N)^T O(N) in MFMA accumulators                  | barrier
+// ---------------------------------------------------------------------------------------------------------
+struct AttnWBLds {
+    float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
+    uint64_t* al;
+};
+__device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
+    AttnWBLds l;
+    l.Win = (float*)smem;
+    l.Wout = l.Win + 192 * DVS_LD;
+    l.inb = l.Wout + 64 * DVS_LD;
+    l.outb = l.inb + 192;
+    l.lg = l.outb + 64;
+    l.lb = l.lg + 64;
+    l.Q = l.lb + 64;
+    l.K = l.Q + DVS_WSCR;
+    l.V = l.K + DVS_WSCR;
+    l.DO = l.V + DVS_WSCR;
+    l.O = l.DO + DVS_WSCR;
+    l.DQ = l.O + DVS_WSCR;
+    l.lse = l.DQ + DVS_WSCR;                     // [8][48]
+    l.delta = l.lse + 8 * DVS_WTOK;              // [8][48]
+    l.al = (uint64_t*)(l.delta + 8 * DVS_WTOK);  // [48] (offset is a multiple of 8 bytes)
+    return l;
+}
+constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 2 * DVS_WTOK;
+
+__global__ __launch_bounds__(256) void k_attn_bwd_w(AttnBwdArgs a) {
+    DVS_DYN_LDS(smem);
+    const AttnWBLds l = attnwb_lds(smem);
+    dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
+    dvs_stage_matrix(l.Wout, DVS_LD, a.out_w, 64, 64, 64);
+    dvs_stage_vector(l.inb, a.in_b, 192);
+    dvs_stage_vector(l.outb, a.out_b, 64);
+    if (a.ln.stats) {
+        dvs_stage_vector(l.lg, a.ln.g, 64);
+        dvs_stage_vector(l.lb, a.ln.b, 64);
+    }
+    for (int i = threadIdx.x; i < 6 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int N = a.dims.N, NT = a.dims.NT, NTOK = 16 * NT, B = a.dims.B;
+    const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
+    const bool has_tile = L.wave < NT;
+    const float scale = 0.35355339059327373f;
+    f4 aWo[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aWo[i][j] = f4_zero();
+    float vbo = 0.f;
+    for (int dag = blockIdx.x; dag < B; dag += gridDim.x) {
+        const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
+        const size_t tile = (size_t)dag * NT + L.wave;
+        const uint32_t gdag = a.dims.dag_offset + dag;
+        const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
+        if (threadIdx.x < DVS_WTOK) l.al[threadIdx.x] = (int)threadIdx.x < N ? rec->allowed[threadIdx.x] : 0ull;
+        f4 dy[4];
+        if (has_tile) {
+            f4 x[4], kv[4], dummy[4];
+            float rstd;
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
+            if (a.kv) {
+                dvs_load_tile(kv, a.kv, tile, L);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kv[t] = x[t];
+            }
+            f4 q[4], k[4], v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                q[t] = dvs_vecT(l.inb, t, L);
+                k[t] = dvs_vecT(l.inb + 64, t, L);
+                v[t] = dvs_vecT(l.inb + 128, t, L);
+            }
+            dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
+            dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
+            dvs_mat_T<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] *= scale;
+            dvs_park_T(l.Q + tok0 * DVS_LD, q, L);
+            dvs_park_T(l.K + tok0 * DVS_LD, k, L);
+            dvs_park_T(l.V + tok0 * DVS_LD, v, L);
+            dvs_load_grad(dy, a.gpre, tile, Nl, L);
+            dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
+            f4 dOT[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
+            dvs_park_T(l.DO + tok0 * DVS_LD, dOT, L);
+        }
+        __syncthreads();
+        // ---- phase A: (query i, head h) ---------------------------------------------------------------------------
+        for (int item = threadIdx.x; item < 8 * N; item += blockDim.x) {
+            const int i = item >> 3, h = item & 7, c0 = 8 * h;
+            const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + c0), q1 = *(const f4*)(l.Q + i * DVS_LD + c0 + 4);
+            const f4 g0 = *(const f4*)(l.DO + i * DVS_LD + c0), g1 = *(const f4*)(l.DO + i * DVS_LD + c0 + 4);
+            const uint64_t al = l.al[i];
+            float mx = -3.0e38f;
+            for (uint64_t m = al; m; m &= m - 1) mx = fmaxf(mx, dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + c0));
+            float den = 0.f;
+            for (uint64_t m = al; m; m &= m - 1) den += __expf(dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + c0) - mx);
+            const float lse = mx + __logf(den);
+            float delta = 0.f;
+            f4 o0 = f4_zero(), o1 = f4_zero();
+            for (uint64_t m = al; m; m &= m - 1) {
+                const int j = dvs_ctz64(m);
+                const float p = __expf(dvs_dot8(q0, q1, l.K + j * DVS_LD + c0) - lse);
+                const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
+                const float* vp = l.V + j * DVS_LD + c0;
+                const float dp = mk * dvs_dot8(g0, g1, vp);
+                delta += p * dp;
+                const float pm = p * mk;
+                o0 += *(const f4*)vp * pm;
+                o1 += *(const f4*)(vp + 4) * pm;
+            }
+            f4 dq0 = f4_zero(), dq1 = f4_zero();
+            for (uint64_t m = al; m; m &= m - 1) {
+                const int j = dvs_ctz64(m);
+                const float* kp = l.K + j * DVS_LD + c0;
+                const float p = __expf(dvs_dot8(q0, q1, kp) - lse);
+                const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
+                const float ds = p * (mk * dvs_dot8(g0, g1, l.V + j * DVS_LD + c0) - delta);
+                dq0 += *(const f4*)kp * ds;
+                dq1 += *(const f4*)(kp + 4) * ds;
+            }
+            *(f4*)(l.O + i * DVS_LD + c0) = o0;
+            *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1;
+            *(f4*)(l.DQ + i * DVS_LD + c0) = dq0 * scale;
+            *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = dq1 * scale;
+            l.lse[h * DVS_WTOK + i] = lse;
+            l.delta[h * DVS_WTOK + i] = delta;
+        }
+        __syncthreads();
+        // ---- phase B: (key j, head h); at most two items per thread (8 * 48 / 256) --------------------------------
+        f4 dkr[2][2], dvr[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            dkr[s][0] = dkr[s][1] = dvr[s][0] = dvr[s][1] = f4_zero();
+            const int item = threadIdx.x + 256 * s;
+            if (item < 8 * N) {
+                const int j = item >> 3, h = item & 7, c0 = 8 * h;
+                for (int i = 0; i < N; ++i) {
+                    if (!((l.al[i] >> j) & 1ull)) continue;
+                    const float* qp = l.Q + i * DVS_LD + c0;
+                    const float* gp = l.DO + i * DVS_LD + c0;
+                    // same operand order as phase A (q . k, dO . v): bitwise the same scores
+                    const f4 qa = *(const f4*)qp, qb = *(const f4*)(qp + 4);
+                    const f4 ga = *(const f4*)gp, gb = *(const f4*)(gp + 4);
+                    const float p = __expf(dvs_dot8(qa, qb, l.K + j * DVS_LD + c0) - l.lse[h * DVS_WTOK + i]);
+                    const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
+                    const float ds = p * (mk * dvs_dot8(ga, gb, l.V + j * DVS_LD + c0) - l.delta[h * DVS_WTOK + i]);
+                    const float pm = p * mk;
+                    dkr[s][0] += qa * ds;
+                    dkr[s][1] += qb * ds;
+                    dvr[s][0] += ga * pm;
+                    dvr[s][1] += gb * pm;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int item = threadIdx.x + 256 * s;
+            if (item < 8 * N) {
+                const int j = item >> 3, c0 = 8 * (item & 7);
+                *(f4*)(l.K + j * DVS_LD + c0) = dkr[s][0];
+                *(f4*)(l.K + j * DVS_LD + c0 + 4) = dkr[s][1];
+                *(f4*)(l.V + j * DVS_LD + c0) = dvr[s][0];
+                *(f4*)(l.V + j * DVS_LD + c0 + 4) = dvr[s][1];
+            }
+        }
+        __syncthreads();
+        if (has_tile) {
+            const bool valid = L.r < Nl;
+            f4 g[4];
+            dvs_lds_T(g, l.DQ, tok0, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = valid ? g[t] : f4_zero();
+            dvs_store_tile(a.gq, tile, g, L);
+            dvs_lds_T(g, l.K, tok0, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = valid ? g[t] : f4_zero();
+            dvs_store_tile(a.gk, tile, g, L);
+            dvs_lds_T(g, l.V, tok0, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = valid ? g[t] : f4_zero();
+            dvs_store_tile(a.gv, tile, g, L);
+            // dWo += dy(N)^T (x) O(N); dbo += column sums of dy.  Q's rows of this tile are free now.
+            dvs_park_T(l.Q + tok0 * DVS_LD, dy, L);
+            dvs_wave_sync();
+            vbo += dvs_colsum(l.Q + tok0 * DVS_LD, L);
+            f4 dyN[4], oN[4];
+            dvs_lds_N(dyN, l.Q, tok0, L);
+            dvs_lds_N(oN, l.O, tok0, L);
+            if (Nl < 16) {       // rows >= Nl of O were never written for this DAG: keep them out of the product
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) oN[t][kk] = (4 * L.g + kk < Nl) ? oN[t][kk] : 0.f;
+            }
+            dvs_outer_acc<4, 4>(aWo, dyN, oN);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)blockIdx.x * a.P;
+    float* region = (float*)smem;
+    dvs_stage_dw<4, 4>(region, aWo, L);
+    float* red = region + DVS_RED_MAT;
+    red[L.wave * 64 + L.lane] = vbo;
+    __syncthreads();
+    dvs_flush_dw<4, 4>(region, slab + a.o_out_w, L);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += red[w * 64 + threadIdx.x];
+        slab[a.o_out_b + threadIdx.x] = s;
+    }
+}
+
+void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
+    size_t lds = ATTNWB_FLOATS * 4;
+    const size_t red = ((size_t)DVS_RED_MAT + 256) * 4;
+    if (lds < red) lds = red;
+    DVS_SET_LDS(k_attn_bwd_w, lds);
+    DVS_LAUNCH(k_attn_bwd_w, dim3(grid), dim3(256), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Loss head backward, wide (autograd of pace.py:1880-1972 + the last decoder LayerNorm; k_loss_bwd restated).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
+    DVS_DYN_LDS(smem);
+    const LossWLds l = lossw_lds(smem);
+    lossw_stage(l, a);
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const int N = a.dims.N, C = a.dims.C, NT = a.dims.NT;
+    const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
+    const bool has_tile = L.wave < NT;
+    const int tok = tok0 + L.r;
+    constexpr int DLD = DVS_WTOK + 1;
+    float* scr = l.scr + L.wave * DVS_SCR;
+    const float b2 = l.b2[0];
+    const float gr = a.gcoef[0];
+    f4 dWn1[2][4], dWn2[3][2], dWa[4][4], dWb[4][4], dbn1[2], dbn2[3], dbe1[4], dw2[4], dgam[4], dbet[4];
+    float db2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dbe1[i] = dw2[i] = dgam[i] = dbet[i] = f4_zero();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dWa[i][j] = dWb[i][j] = f4_zero();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dbn1[i] = f4_zero();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dWn1[i][j] = f4_zero();
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dbn2[i] = f4_zero();
+        dWn2[i][0] = dWn2[i][1] = f4_zero();
+    }
+    for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
+        const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
+        const size_t tile = (size_t)dag * NT + L.wave;
+        f4 h[4], xhat[4], hN[4], dh[4], U[4], V[4], w2v[4], dU[4], dV[4];
+        float rstd = 1.f;
+        if (has_tile) {
+            dvs_load_x<true>(h, xhat, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
+            dvs_t2n<4>(hN, h, scr, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dh[t] = f4_zero();
+            // ---- node head --------------------------------------------------------------------------------------
+            {
+                f4 t1p[2], t1[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) t1p[t] = dvs_vecT(l.bn1, t, L);
+                dvs_mat_T<2, 4>(t1p, h, l.Wn1, DVS_LD, 0, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) t1[t][kk] = fmaxf(t1p[t][kk], 0.f);
+                f4 lgt[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) lgt[ct] = *(const f4*)(l.bn2 + 16 * ct + 4 * L.g);
+                dvs_mat_T<3, 2>(lgt, t1, l.Wn2, LOSSW_LDN2, 0, L);
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) mx = (16 * ct + 4 * L.g + reg < C) ? fmaxf(mx, lgt[ct][reg]) : mx;
+                mx = dvs_max_g(mx);
+                f4 ex[3];
+                float se = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        ex[ct][reg] = (16 * ct + 4 * L.g + reg < C) ? __expf(lgt[ct][reg] - mx) : 0.f;
+                        se += ex[ct][reg];
+                    }
+                se = dvs_sum_g(se);
+                const int target = rec->label[tok + 1 < DVS_WTOK ? tok + 1 : 0];
+                const bool vt = tok < N - 1;
+                f4 dlg[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = 16 * ct + 4 * L.g + reg;
+                        dlg[ct][reg] = (vt && c < C) ? gr * (ex[ct][reg] / se - (c == target ? 1.f : 0.f)) : 0.f;
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) dbn2[ct] += dlg[ct];
+                f4 dlgN[3], t1N[2];
+                dvs_t2n<3>(dlgN, dlg, scr, L);
+                dvs_t2n<2>(t1N, t1, scr, L);
+                dvs_outer_acc<3, 2>(dWn2, dlgN, t1N);
+                f4 dt1[2] = {f4_zero(), f4_zero()};
+                dvs_mat_Tt<2, 3>(dt1, dlg, l.Wn2, LOSSW_LDN2, 0, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) dt1[t][kk] = t1p[t][kk] > 0.f ? dt1[t][kk] : 0.f;
+                    dbn1[t] += dt1[t];
+                }
+                f4 dt1N[2];
+                dvs_t2n<2>(dt1N, dt1, scr, L);
+                dvs_outer_acc<2, 4>(dWn1, dt1N, hN);
+                dvs_mat_Tt<4, 2>(dh, dt1, l.Wn1, DVS_LD, 0, L);
+            }
+            // ---- edge head: U, V of this tile; both parked for the other tiles ------------------------------------
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                U[t] = f4_zero();
+                V[t] = dvs_vecT(l.be1, t, L);
+                w2v[t] = dvs_vecT(l.w2, t, L);
+                dU[t] = dV[t] = f4_zero();
+            }
+            dvs_mat_T<4, 4>(U, h, l.Wa, DVS_LD, 0, L);
+            dvs_mat_T<4, 4>(V, h, l.Wb, DVS_LD, 0, L);
+            dvs_park_T(l.V + tok0 * DVS_LD, V, L);
+            dvs_park_T(l.U + tok0 * DVS_LD, U, L);
+        }
+        __syncthreads();
+        if (has_tile) {
+            // pass 1: lane r = token i walks j < i; accumulates dU, dw2, db2; publishes d logit(i, j)
+            const uint64_t par = rec->parents[tok + 1 < DVS_WTOK ? tok + 1 : 0];
+            const int jend = (N - 2 < tok0 + 15) ? N - 2 : tok0 + 15;
+            for (int j = 0; j < jend; ++j) {
+                f4 pre[4];
+                float e = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f4 vj = *(const f4*)(l.V + j * DVS_LD + 16 * t + 4 * L.g);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        pre[t][kk] = fmaxf(U[t][kk] + vj[kk], 0.f);
+                        e += w2v[t][kk] * pre[t][kk];
+                    }
+                }
+                const float logit = dvs_sum_g(e) + b2;
+                const bool pv = (tok > j) && (tok <= N - 2);
+                const float truth = (float)((par >> (j + 1)) & 1ull);
+                const float sg = 1.0f / (1.0f + __expf(-logit));
+                const float dl = pv ? gr * (sg - truth) : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        dw2[t][kk] += dl * pre[t][kk];
+                        dU[t][kk] += pre[t][kk] > 0.f ? dl * w2v[t][kk] : 0.f;
+                    }
+                if (L.g == 0) {
+                    db2 += dl;
+                    l.dlm[tok * DLD + j] = dl;
+                }
+            }
+        }
+        __syncthreads();
+        if (has_tile) {
+            // pass 2: lane r = token j walks i > j; accumulates dV
+            const int i0 = tok0 + 1 > 1 ? tok0 + 1 : 1;
+            for (int i = i0; i <= N - 2; ++i) {
+                const float dl = (tok < i) ? l.dlm[i * DLD + tok] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f4 ui = *(const f4*)(l.U + i * DVS_LD + 16 * t + 4 * L.g);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) dV[t][kk] += (ui[kk] + V[t][kk] > 0.f) ? dl * w2v[t][kk] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dbe1[t] += dV[t];
+            f4 dUN[4], dVN[4];
+            dvs_t2n<4>(dUN, dU, scr, L);
+            dvs_t2n<4>(dVN, dV, scr, L);
+            dvs_outer_acc<4, 4>(dWa, dUN, hN);
+            dvs_outer_acc<4, 4>(dWb, dVN, hN);
+            dvs_mat_Tt<4, 4>(dh, dU, l.Wa, DVS_LD, 0, L);
+            dvs_mat_Tt<4, 4>(dh, dV, l.Wb, DVS_LD, 0, L);
+            dvs_ln_bwd(dh, xhat, rstd, l.lg, dgam, dbet, L);
+            dvs_store_tile(a.gout, tile, dh, L);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)blockIdx.x * a.P;
+    {
+        float* rA = (float*)smem;
+        float* rB = rA + DVS_RED_MAT;
+        dvs_stage_dw<4, 4>(rA, dWa, L);
+        dvs_stage_dw<4, 4>(rB, dWb, L);
+        __syncthreads();
+        dvs_flush_dw<4, 4>(rA, slab + a.o_edge0_w, L, 64, 128);
+        dvs_flush_dw<4, 4>(rB, slab + a.o_edge0_w + 64, L, 64, 128);
+        __syncthreads();
+        float* rN1 = (float*)smem;                      // 4 * 2048
+        float* rN2 = rN1 + 4 * 2048;                    // 4 * 1536
+        float* rv1 = rN2 + 4 * 1536;                    // dbn1: 4 * 32
+        float* rv2 = rv1 + 4 * 32;                      // dbn2: 4 * 48
+        float* rv3 = rv2 + 4 * 48;                      // dbe1, dw2, dgam, dbet: 4 * 64 each
+        float* rb2 = rv3 + 4 * DVS_RED_VEC;             // 16
+        float* es = rb2 + 16 + L.wave * DVS_SCR;
+        dvs_stage_dw<2, 4>(rN1, dWn1, L);
+        dvs_stage_dw<3, 2>(rN2, dWn2, L);
+        dvs_stage_vec<2>(rv1, dbn1, es, L);
+        dvs_stage_vec<3>(rv2, dbn2, es, L);
+        dvs_stage_vec<4>(rv3, dbe1, es, L);
+        dvs_stage_vec<4>(rv3 + DVS_RED_VEC, dw2, es, L);
+        dvs_stage_vec<4>(rv3 + 2 * DVS_RED_VEC, dgam, es, L);
+        dvs_stage_vec<4>(rv3 + 3 * DVS_RED_VEC, dbet, es, L);
+        const float sb2 = dvs_sum_wave(L.g == 0 ? db2 : 0.f);
+        if (L.lane == 0) rb2[L.wave] = sb2;
+        __syncthreads();
+        dvs_flush_dw<2, 4>(rN1, slab + a.o_node0_w, L);
+        dvs_flush_dw<3, 2>(rN2, slab + a.o_node2_w, L, C, 32);
+        dvs_flush_vec<2>(rv1, slab + a.o_node0_b, L);
+        dvs_flush_vec<3>(rv2, slab + a.o_node2_b, L, C);
+        dvs_flush_vec<4>(rv3, slab + a.o_edge0_b, L);
+        dvs_flush_vec<4>(rv3 + DVS_RED_VEC, slab + a.o_edge2_w, L);
+        dvs_flush_vec<4>(rv3 + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
+        dvs_flush_vec<4>(rv3 + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
+        if (threadIdx.x == 0) {
+            float s = rb2[0];
+            for (int w = 1; w < L.nwaves; ++w) s += rb2[w];
+            slab[a.o_edge2_b] = s;
+        }
+    }
+}
+
+void dvs_launch_loss_bwd_w(const LossArgs& a, int grid, dvs_stream_t st) {
+    size_t lds = dvs_lossw_lds_floats() * 4;
+    const size_t red = (2 * (size_t)DVS_RED_MAT) * 4;
+    if (lds < red) lds = red;
+    DVS_SET_LDS(k_loss_bwd_w, lds);
+    DVS_LAUNCH(k_loss_bwd_w, dim3(grid), dim3(256), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding backward, wide (autograd of pace.py:201-221, 1181-1184).  The forward's row gathers become row scatters;
+// here they are OWNER-COMPUTES: thread (row p, feature f) of W1 keeps its gradient element in a register and, per DAG,
+// pulls the rows of the parked d e1 tile that the DAG maps to p (tokens at position p; tokens with a parent at
+// position p) — no atomics, fixed summation order.  Same for the label table (class c <- tokens labelled c).
+// Up to two gradient sources per DAG (encoder- and decoder-side embeddings share weights and the scatter pattern, so
+// their d e1 are added before parking).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EMBW_DLE_LD = 36;
+constexpr int EMBW_W1_PER_THREAD = 2 * DVS_WTOK * 64 / 256;      // 24
+constexpr int EMBW_LAB_PER_THREAD = 32 * DVS_WTOK / 256;         // 6
+__global__ __launch_bounds__(256) void k_embed_bwd_w(EmbedArgs a, const float* gout2, int site2) {
+    DVS_DYN_LDS(smem);
+    const EmbWLds l = embw_lds(smem);
+    float* DE1 = (float*)smem + EMBW_FLOATS;                     // [48][LD]
+    float* DLE = DE1 + DVS_WSCR;                                 // [48][36]
+    float* scr0 = DLE + DVS_WTOK * EMBW_DLE_LD;                  // 4 per-wave transpose tiles
+    uint64_t* posmask = (uint64_t*)(scr0 + 4 * DVS_SCR);         // [48] tokens at position p
+    uint64_t* parmask = posmask + DVS_WTOK;                      // [48] tokens with a parent at position p
+    uint64_t* labmask = parmask + DVS_WTOK;                      // [48] tokens labelled c
+    uint64_t* parents = labmask + DVS_WTOK;                      // [48]
+    embw_stage(l, a);
+    for (int i = threadIdx.x; i < DVS_WSCR + DVS_WTOK * EMBW_DLE_LD; i += blockDim.x) DE1[i] = 0.f;
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int N = a.dims.N, C = a.dims.C, NT = a.dims.NT;
+    const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
+    const bool has_tile = L.wave < NT;
+    float* scr = scr0 + L.wave * DVS_SCR;
+    float aW1[EMBW_W1_PER_THREAD], alab[EMBW_LAB_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) aW1[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) alab[k] = 0.f;
+    f4 dW2[4][2], dlabb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dW2[i][0] = dW2[i][1] = f4_zero();
+    dlabb[0] = dlabb[1] = f4_zero();
+    const int fW = threadIdx.x & 63;              // this thread's W1 column; rows (threadIdx.x >> 6) + 4k
+    const int fL = threadIdx.x & 31;              // label table: feature fL, classes (threadIdx.x >> 5) + 8k
+    for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
+        const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
+        const size_t tile = (size_t)dag * NT + L.wave;
+        const uint32_t gdag = a.dims.dag_offset + dag;
+        if (threadIdx.x < DVS_WTOK) {
+            const int p = threadIdx.x;
+            uint64_t pm = 0, lm = 0;
+            for (int i = 0; i < N; ++i) {
+                if (rec->pos[i] == p) pm |= 1ull << i;
+                if (rec->label[i] == p) lm |= 1ull << i;
+            }
+            uint64_t qm = 0;
+            for (int i = 0; i < N; ++i)
+                if (rec->parents[i] & pm) qm |= 1ull << i;
+            posmask[p] = pm;
+            parmask[p] = qm;
+            labmask[p] = lm;
+            parents[p] = p < N ? rec->parents[p] : 0ull;
+        }
+        if (has_tile) {
+            const bool valid = L.r < Nl;
+            const int label = rec->label[valid ? tok0 + L.r : 0];
+            f4 e1[4];
+            embw_hidden(e1, l.W1, rec, N, tok0, Nl, L);
+            f4 de1s[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, dles[2] = {f4_zero(), f4_zero()};
+            for (int src = 0; src < 2; ++src) {
+                const float* gsrc = src == 0 ? a.gout : gout2;
+                if (!gsrc) continue;
+                const int site = src == 0 ? a.site : site2;
+                f4 gx[4];
+                dvs_load_grad(gx, gsrc, tile, Nl, L);
+                f4 dle[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int f = 16 * t + 4 * L.g + kk;
+                        const float pre = l.labw[f * EMBW_LABLD + label] + l.labb[f];
+                        dle[t][kk] = (valid && pre > 0.f) ? gx[t][kk] : 0.f;
+                    }
+                dlabb[0] += dle[0];
+                dlabb[1] += dle[1];
+                dles[0] += dle[0];
+                dles[1] += dle[1];
+                f4 e1d[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e1d[t] = e1[t];
+                const uint32_t k1 = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site, gdag);
+                dvs_dropout_tile(e1d, k1, D, L, tok0);
+                f4 de2[2];
+                {
+                    f4 tmp[4] = {gx[2], gx[3], f4_zero(), f4_zero()};
+                    dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L, tok0);
+                    de2[0] = tmp[0];
+                    de2[1] = tmp[1];
+                }
+                f4 e1dN[4], de2N[2];
+                dvs_t2n<4>(e1dN, e1d, scr, L);
+                dvs_t2n<2>(de2N, de2, scr, L);
+                dvs_outer_acc<4, 2>(dW2, e1dN, de2N);
+                f4 de1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+                dvs_mat_T<4, 2>(de1, de2, l.W2, EMB_LDW2, 0, L);
+                dvs_dropout_tile(de1, k1, D, L, tok0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) de1s[t][kk] += e1[t][kk] > 0.f ? de1[t][kk] : 0.f;
+            }
+            dvs_park_T(DE1 + tok0 * DVS_LD, de1s, L);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) *(f4*)(DLE + (tok0 + L.r) * EMBW_DLE_LD + 16 * t + 4 * L.g) = dles[t];
+        }
+        __syncthreads();
+        // ---- owner-computes scatters ---------------------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) {
+            const int prow = (threadIdx.x >> 6) + 4 * k;
+            if (prow < N) {
+                for (uint64_t m = posmask[prow]; m; m &= m - 1) aW1[k] += DE1[dvs_ctz64(m) * DVS_LD + fW];
+            } else if (prow < 2 * N) {
+                const uint64_t pm = posmask[prow - N];
+                for (uint64_t m = parmask[prow - N]; m; m &= m - 1) {
+                    const int i = dvs_ctz64(m);
+                    aW1[k] += (float)__popcll(parents[i] & pm) * DE1[i * DVS_LD + fW];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) {
+            const int c = (threadIdx.x >> 5) + 8 * k;
+            if (c < C)
+                for (uint64_t m = labmask[c]; m; m &= m - 1) alab[k] += DLE[dvs_ctz64(m) * EMBW_DLE_LD + fL];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)blockIdx.x * a.P;
+#pragma unroll
+    for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) {
+        const int prow = (threadIdx.x >> 6) + 4 * k;
+        if (prow < 2 * N) slab[a.oW1 + (size_t)prow * 64 + fW] = aW1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) {
+        const int c = (threadIdx.x >> 5) + 8 * k;
+        if (c < C) slab[a.olab_w + (size_t)fL * C + c] = alab[k];
+    }
+    float* rW2 = (float*)smem;                 // 4 * 2048
+    float* rv = rW2 + 4 * 2048;                // 4 * 32
+    dvs_stage_dw<4, 2>(rW2, dW2, L);
+    dvs_stage_vec<2>(rv, dlabb, rv + 4 * 32 + L.wave * DVS_SCR, L);
+    __syncthreads();
+    dvs_flush_dw<4, 2>(rW2, slab + a.oW2, L);
+    dvs_flush_vec<2>(rv, slab + a.olab_b, L);
+}
+
+void dvs_launch_embed_bwd_w(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
+    size_t lds = (EMBW_FLOATS + DVS_WSCR + DVS_WTOK * EMBW_DLE_LD + 4 * DVS_SCR + 2 * 4 * DVS_WTOK) * 4;
+    const size_t red = (4 * 2048 + 4 * 32 + 4 * (size_t)DVS_SCR) * 4;
+    if (lds < red) lds = red;
+    DVS_SET_LDS(k_embed_bwd_w, lds);
+    DVS_LAUNCH(k_embed_bwd_w, dim3(grid), dim3(256), lds, st, a, gout2, site2);
+}

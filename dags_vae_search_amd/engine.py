@@ -38,6 +38,9 @@ class PaceEngine:
         if self.lib.dvs_param_count(ctypes.byref(shape)) < 0:
             dl.check(self.lib, 1, "dvs_param_count")
         self.table, self.param_floats = dl.param_table(self.lib, shape)
+        self.record_bytes = dl.record_bytes(self.lib, shape)
+        self.wide = dl.is_wide(self.n_tokens, self.n_classes)
+        self.tiles = (self.n_tokens + dl.TILE_TOKENS - 1) // dl.TILE_TOKENS
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
         self._records: Optional[torch.Tensor] = None
@@ -55,7 +58,7 @@ class PaceEngine:
                 dl.check(self.lib, 1, "dvs_workspace_bytes")
             self._ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)   # slab padding must stay 0
             self._ws_batch = batch
-            self._records = torch.empty(batch * dl.RECORD_BYTES, dtype=torch.uint8, device=device)
+            self._records = torch.empty(batch * self.record_bytes, dtype=torch.uint8, device=device)
             self._status = torch.zeros(1, dtype=torch.int32, device=device)
         return self._ws
 
@@ -96,14 +99,15 @@ class PaceEngine:
         return self._records
 
     def build_records(self, labels: torch.Tensor, preds: torch.Tensor, check: bool = True) -> torch.Tensor:
-        """dvs_build_records: row codec (labels u8 [B,n], preds i16/u16 [B,n]) -> records, all on the device."""
+        """dvs_build_records: row codec (labels u8 [B,n], preds [B,n]: i16 bit pattern of u16 masks on the one-tile
+        path, i64 on the wide path) -> records, all on the device."""
         _require_cuda(labels, "labels")
         _require_cuda(preds, "preds")
         B, n = labels.shape
         if n != self.n_tokens - 3 or tuple(preds.shape) != (B, n):
             raise AssertionError(f"Expected {self.n_tokens - 3}, got instead {n}")
         labels = labels.contiguous().to(torch.uint8)
-        preds = preds.contiguous().to(torch.int16)
+        preds = preds.contiguous().to(torch.int64 if self.wide else torch.int16)
         self.workspace(B, labels.device)
         self._status.zero_()
         shape = self.shape(B)
@@ -140,7 +144,7 @@ class PaceEngine:
                                                   _ptr(scratch), _stream()), "dvs_clip_adam")
 
     def activation(self, batch: int, slot: int) -> torch.Tensor:
-        out = torch.empty(batch, 16, 64, dtype=torch.float32, device=self._ws.device)
+        out = torch.empty(batch, 16 * self.tiles, 64, dtype=torch.float32, device=self._ws.device)
         shape = self.shape(batch)
         dl.check(self.lib, self.lib.dvs_debug_activation(ctypes.byref(shape), _ptr(self._ws), slot, _ptr(out), _stream()),
                  "dvs_debug_activation")

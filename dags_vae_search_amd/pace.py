@@ -6,7 +6,8 @@ Same constructor arguments, properties, state-dict keys/shapes (108 tensors), ``
 Differences a user can observe:
   * the model must live on a GPU for any compute (`.to("cuda")`); there is no CPU path;
   * only the BASELINE architecture is built (embedding 32, 8 heads, 3 layers, width 64, latent 32, fc_hidden 32,
-    max_num_vertices <= 13, cardinality <= 13) — anything else raises NotImplementedError;
+    max_num_vertices <= 45, cardinality <= 45: up to 13 on the one-wave-per-DAG kernels, beyond that on the tiled
+    workgroup-per-DAG kernels) — anything else raises NotImplementedError;
   * dropout masks / reparameterisation noise come from a counter-based generator keyed by (seed, step, DAG index)
     instead of torch's global generator (``model.seed(s)`` re-seeds it; ``eps=`` injects the noise);
   * ``decode`` (generation, pace.py:1666-1749) is outside this path and raises NotImplementedError.
@@ -126,9 +127,9 @@ class PaceVaeV3(nn.Module):
                      ff_hidden_size=ff_hidden_size, latent_layer_size=latent_layer_size, fc_hidden=fc_hidden)
         if given != built:
             raise NotImplementedError(f"this MI355X build implements the BASELINE architecture {built}; got {given}")
-        if max_num_vertices + 3 > dl.MAX_TOKENS or vertex_label_cardinality + 3 > 16 or max_num_vertices < 1:
-            raise NotImplementedError("this build supports max_num_vertices <= 13 and vertex_label_cardinality <= 13 "
-                                      "(one 16-token tile per DAG); larger graphs (alarm, n=37) are a later round")
+        if max_num_vertices + 3 > dl.MAX_TOKENS or vertex_label_cardinality + 3 > dl.MAX_TOKENS or max_num_vertices < 1:
+            raise NotImplementedError("this build supports max_num_vertices <= 45 and vertex_label_cardinality <= 45 "
+                                      "(up to three 16-token tiles per DAG)")
         self._max_num_vertices = max_num_vertices + 3          # pace.py:1159
         self._vertex_label_cardinality = vertex_label_cardinality + 3
         self.vertices_embedding_size = vertices_embedding_size

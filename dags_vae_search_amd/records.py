@@ -3,7 +3,8 @@
 The reference turns every parquet row into an igraph object, wraps it, and builds ~7.7 KB of dense float/bool features
 per DAG in Python (pace.py:1345-1478), then ``torch.cat``s B of those dicts per step (main.py:75-92).  Once the train
 step takes 2.5 ms that host work would dominate by orders of magnitude.  Here a DAG is its row codec in 3 bytes per
-vertex — ``labels[v]`` (u8) and ``preds[v]`` (u16, bit u <=> edge u -> v, the ``e{v}`` string) — kept ON the GPU for
+vertex (11 for n > 13) — ``labels[v]`` (u8) and ``preds[v]`` (u16, or u64 when n > 13; bit u <=> edge u -> v, the
+``e{v}`` string) — kept ON the GPU for
 the whole dataset; a batch is an index gather, and ``dvs_build_records`` (HIP) does the PACE wrapping, FIFO-Kahn
 positions and ancestor closure per DAG.  ``PaceVaeV3.loss_direct`` / ``encode_direct`` / ``train_batch`` accept a
 ``CompactBatch`` wherever they accept the reference's feature dict.
@@ -22,7 +23,7 @@ from .features import LabeledGraph, _as_labels_edges
 @dataclass
 class CompactBatch:
     labels: torch.Tensor      # [B, n] uint8
-    preds: torch.Tensor       # [B, n] int16 (bit pattern of the u16 predecessor mask)
+    preds: torch.Tensor       # [B, n] int16 (bit pattern of the u16 predecessor mask); int64 when n > 13 (wide path)
 
     def __len__(self) -> int:
         return self.labels.shape[0]
@@ -39,7 +40,9 @@ def encode_graphs(graphs: Sequence, n: int, label_key: str = "type") -> CompactB
     (``l{v}``, ``e{v}``).  Edges must go from lower to higher vertex id (the codec's order, labeled.py:132-154)."""
     B = len(graphs)
     labels = np.zeros((B, n), np.uint8)
-    preds = np.zeros((B, n), np.uint16)
+    wide = n > 13                      # n + 3 tokens > one 16-token tile: 64-bit predecessor rows
+    udt, sdt = (np.uint64, np.int64) if wide else (np.uint16, np.int16)
+    preds = np.zeros((B, n), udt)
     for b, g in enumerate(graphs):
         if isinstance(g, dict):
             for v in range(n):
@@ -59,13 +62,14 @@ def encode_graphs(graphs: Sequence, n: int, label_key: str = "type") -> CompactB
         for u, v in edges:
             if not (0 <= u < v < n):
                 raise ValueError("compact encoding needs edges u -> v with u < v (topological vertex order)")
-            preds[b, v] |= np.uint16(1 << u)
-    return CompactBatch(torch.from_numpy(labels), torch.from_numpy(preds.view(np.int16)))
+            preds[b, v] |= udt(1 << u)
+    return CompactBatch(torch.from_numpy(labels), torch.from_numpy(preds.view(sdt)))
 
 
 def decode_graphs(batch: CompactBatch):
     lab = batch.labels.cpu().numpy()
-    pr = batch.preds.cpu().numpy().view(np.uint16)
+    pr = batch.preds.cpu().numpy()
+    pr = pr.view(np.uint64 if pr.dtype == np.int64 else np.uint16)
     out = []
     for b in range(lab.shape[0]):
         edges = [(u, v) for v in range(lab.shape[1]) for u in range(v) if (int(pr[b, v]) >> u) & 1]

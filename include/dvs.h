@@ -14,7 +14,9 @@
  *
  * Fixed architecture of this build (BASELINE.json configs; experiments/01_bn_asia/main.py:33-43):
  * vertices_embedding_size 32, num_heads 8, num_layers 3, ff_hidden_size 64, latent_layer_size 32,
- * fc_hidden 32.  n_tokens = n + 3 <= 16, n_classes = card + 3 <= 16.
+ * fc_hidden 32.  n_tokens = n + 3 <= 48, n_classes = card + 3 <= 48.  Shapes with n_tokens <= 16 and n_classes <= 16
+ * (asia, sachs, n = 12) take the one-tile path (a wavefront owns a DAG); larger ones (alarm-size, n = 37) the tiled
+ * "wide" path (a workgroup owns a DAG, tiles of 16 tokens meet in LDS).  Same entry points for both.
  */
 #ifndef DVS_H
 #define DVS_H
@@ -28,13 +30,14 @@ extern "C" {
 
 #define DVS_VERSION 100
 #define DVS_NUM_PARAMS 108
-#define DVS_RECORD_BYTES 96
+#define DVS_RECORD_BYTES 96          /* one-tile path */
+#define DVS_RECORD_BYTES_WIDE 864    /* wide path; dvs_record_bytes(shape) returns the one that applies */
 #define DVS_CLIP_SCRATCH_FLOATS 320
 
 typedef struct dvs_shape {
     int32_t batch;        /* DAGs in this (rank-local) batch */
-    int32_t n_tokens;     /* N = max_num_vertices + 3 (pace.py:1159), <= 16 */
-    int32_t n_classes;    /* C = vertex_label_cardinality + 3 (pace.py:1160), <= 16 */
+    int32_t n_tokens;     /* N = max_num_vertices + 3 (pace.py:1159), <= 48 */
+    int32_t n_classes;    /* C = vertex_label_cardinality + 3 (pace.py:1160), <= 48 */
     int32_t training;     /* 1 = model.train(): dropout + reparameterisation noise; 0 = eval */
     float dropout;        /* p of every nn.Dropout / attention dropout (pace.py:1150) */
     float beta;           /* KL weight (pace.py:1977) */
@@ -61,10 +64,13 @@ int dvs_param_table(const dvs_shape* s, dvs_param_entry* out, int cap);
 /* Scratch needed by forward+backward for s->batch DAGs (saved activations, gradient slabs). */
 size_t dvs_workspace_bytes(const dvs_shape* s);
 
+/* Bytes of one compact per-DAG record for this shape (96 or 864); the caller allocates batch * this. */
+size_t dvs_record_bytes(const dvs_shape* s);
+
 /* Replaces the `.to(device)` feature hand-over at pace.py:1981-1985 / 1616-1619: reads the reference-layout
  * dense features — vertex_label_features [B,N,C] f32, vertex_position_features [B,N,N] f32,
- * adjacency_matrices [B,N,N] f32, target_masks [8B,N,N] bool (1 byte each) — and writes one 96-byte
- * compact record per DAG.  status (device int32[1], zeroed by the caller) gets bit 0 set if a label/position
+ * adjacency_matrices [B,N,N] f32, target_masks [8B,N,N] bool (1 byte each) — and writes one compact record
+ * (dvs_record_bytes) per DAG.  status (device int32[1], zeroed by the caller) gets bit 0 set if a label/position
  * row is not one-hot, bit 1 if the 8 per-head masks of a DAG differ, bit 2 if a mask row forbids self. */
 int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
                       const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
@@ -73,10 +79,10 @@ int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float
 /* Device-side feature front-end (replaces LabeledDag.from_dict_to_graph src/toolkit/labeled.py:132-154 +
  * from_labeled_graph_to_pace_graph pace.py:1250-1288 + generate_mask 1307-1343 + prepare_features 1345-1478 + pack):
  * builds the records straight from the row codec.  labels: device u8 [B][n] (n = n_tokens - 3, l{v} columns);
- * preds: device u16 [B][n], bit u of preds[b][v] set <=> edge u -> v (the e{v} '0/1' string, u < v).  One thread per
- * DAG does the PACE wrapping, the FIFO-Kahn topological order (positions[v] = order[v], the reference's quirk), and
- * the ancestor closure on 16-bit rows.  status bit 0: a label is >= n_classes - 3; bit 3: an edge with u >= v. */
-int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const uint16_t* preds, void* records, int32_t* status,
+ * preds: device [B][n], bit u of preds[b][v] set <=> edge u -> v (the e{v} '0/1' string, u < v); element type u16 on
+ * the one-tile path (dvs_record_bytes == 96), u64 on the wide path.  One thread per DAG does the PACE wrapping, the
+ * FIFO-Kahn topological order (positions[v] = order[v], the reference's quirk), and the ancestor closure on bit rows.  status bit 0: a label is >= n_classes - 3; bit 3: an edge with u >= v. */
+int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* preds, void* records, int32_t* status,
                       void* stream);
 
 /* PaceVaeV3.loss_direct forward (pace.py:1974-2035).  eps: optional device [B,32] noise already multiplied
@@ -109,7 +115,7 @@ int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float*
 void dvs_profile_enable(int on);
 int dvs_profile_collect(char* names, int name_stride, int* counts, float* total_ms, int cap);
 
-/* Debug/test access: copy saved activation `slot` (natural [B,16,64] layout) out of the workspace. */
+/* Debug/test access: copy saved activation `slot` (natural [B, 16*ceil(n_tokens/16), 64] layout) out of the workspace. */
 int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -66,13 +66,15 @@ class DeviceMasks:
         return keep.astype(np.float32) * self.scale
 
     def attn(self, site: int, B: int, N: int, heads: int = 8):
-        """[B*heads, N, N] mask*scale for attention probabilities: element = (h*16 + i)*16 + j."""
+        """[B*heads, N, N] mask*scale for attention probabilities: element = (h*T + i)*T + j with T = 16*ceil(N/16)
+        token slots per DAG (16 on the one-tile path)."""
+        T = np.uint64(16 * ((N + 15) // 16))
         dag = np.arange(B, dtype=np.uint64) + np.uint64(self.dag_offset)
         key = site_key(self.seed, site, dag)[:, None, None, None]
         h = np.arange(heads, dtype=np.uint64)[None, :, None, None]
         i = np.arange(N, dtype=np.uint64)[None, None, :, None]
         j = np.arange(N, dtype=np.uint64)[None, None, None, :]
-        keep = keep_elements(key, (h * np.uint64(16) + i) * np.uint64(16) + j, self.thr16)
+        keep = keep_elements(key, (h * T + i) * T + j, self.thr16)
         return (keep.astype(np.float32) * self.scale).reshape(B * heads, N, N)
 
     def eps(self, B: int, latent: int = 32):

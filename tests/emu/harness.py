@@ -33,7 +33,8 @@ class EmuModel:
             v = np.asarray(params[name], np.float32).reshape(-1)
             self.flat[off:off + v.size] = v
         self.ws = np.zeros(self.lib.dvs_workspace_bytes(ctypes.byref(self.shape)) // 4 + 64, np.float32)
-        self.records = np.zeros(batch * dl.RECORD_BYTES, np.uint8)
+        self.record_bytes = dl.record_bytes(self.lib, self.shape)
+        self.records = np.zeros(batch * self.record_bytes, np.uint8)
         self.batch = batch
 
     def pack(self, feats):
@@ -63,7 +64,7 @@ class EmuModel:
         return {name: grads[off:off + int(np.prod(shp))].reshape(shp) for name, off, shp in self.table}, grads
 
     def activation(self, slot):
-        out = np.zeros((self.batch, 16, 64), np.float32)
+        out = np.zeros((self.batch, 16 * ((self.cfg.N + 15) // 16), 64), np.float32)
         dl.check(self.lib, self.lib.dvs_debug_activation(ctypes.byref(self.shape), ptr(self.ws), slot, ptr(out), None),
                  "debug_activation")
         return out

@@ -14,8 +14,8 @@ Fixtures written (data only — inputs and expected outputs):
   asia_known_answer.npz   256 rows of experiments/01_bn_asia/data/test/part.0.parquet (labels + edge
                           strings) matched to their ``mu`` vectors in predictor_dataset/part-*.parquet
                           (written by the reference's prepare_predictor_data, main.py:268-303)
-  golden_<cfg>.npz        for cfg in {asia, asia_rand (synthetic n=8 graphs, ckpt 110), n12c1, n12c12 (fresh-seed
-                          parameters, stored under param/)}: graphs -> reference outputs: eval-mode
+  golden_<cfg>.npz        for cfg in {asia, asia_rand (synthetic n=8 graphs, ckpt 110), n12c1, n12c12 and n37c37
+                          (alarm-size; fresh-seed parameters, stored under param/; n37c37 is 'slim')}: graphs -> reference outputs: eval-mode
                           (total, recon, kld, mu, logvar, decoder_output) + all gradients; train-mode
                           with dropout=0 and the captured eps: same + gradients; and one train_batch
                           golden (params after one clip+Adam step, eval-mode gradients excluded)
@@ -114,7 +114,8 @@ def grads_of(model):
     return {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters()}
 
 
-def golden(PaceVaeV3, name, n, card, sd, graphs, seed):
+def golden(PaceVaeV3, name, n, card, sd, graphs, seed, slim=False):
+    """slim: keep the fixture small for big models — no train-mode gradients and no train_batch golden."""
     out = {}
     feats_np = ofeat.dense_features(graphs, card)
     f = ofeat.to_torch(feats_np)
@@ -158,6 +159,10 @@ def golden(PaceVaeV3, name, n, card, sd, graphs, seed):
     out["train0/eps"] = eps.numpy()
     out["train0/total"], out["train0/recon"], out["train0/kld"] = (np.float64(total.item()), np.float64(recon.item()),
                                                                    np.float64(kld.item()))
+    if slim:
+        np.savez_compressed(os.path.join(HERE, f"golden_{name}.npz"), **out)
+        print(f"golden_{name}: B={len(graphs)} eval total={out['eval/total']:.6f} | train0 total={out['train0/total']:.6f}")
+        return
     for k, g in grads_of(model0).items():
         out["train0/grad/" + k] = g
 
@@ -186,6 +191,21 @@ def main():
     golden(PaceVaeV3, "asia_rand", 8, 8, sd_asia, ofeat.synthetic_dags(8, 8, 48, seed=10), seed=6)
     golden(PaceVaeV3, "n12c1", 12, 1, sd_n12, ofeat.synthetic_dags(12, 1, 48, seed=11), seed=8)
     golden(PaceVaeV3, "n12c12", 12, 12, None, ofeat.synthetic_dags(12, 12, 48, seed=12), seed=9)
+    golden(PaceVaeV3, "n37c37", 37, 37, None, alarm_graphs(), seed=10, slim=True)
+
+
+def alarm_graphs():
+    """BASELINE config 5: alarm-size (n = 37) synthetic DAGs, density <= 0.2 (README.md:53-56), plus deep chains
+    (37-level topological order) that stress the ancestor mask / parent gather."""
+    n = 37
+    graphs = ofeat.synthetic_dags(n, n, 12, seed=13, density_limit=0.2)
+    rng = np.random.default_rng(14)
+    chain = [(v, v + 1) for v in range(n - 1)]
+    graphs.append(([int(x) for x in rng.permutation(n)], chain))                                   # pure path
+    graphs.append(([int(x) for x in rng.permutation(n)], sorted(set(chain + [(v, v + 3) for v in range(0, n - 3, 2)]))))
+    graphs.append(([int(x) for x in rng.permutation(n)], [(0, v) for v in range(1, n)]))            # star: one source
+    graphs.append(([int(x) for x in rng.permutation(n)], [(v, n - 1) for v in range(n - 1)]))       # 36 parents of one sink
+    return graphs
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ CONFIGS = {
     "asia_rand": dict(n=8, card=8, ckpt="asia_ckpt110.npz"),
     "n12c1": dict(n=12, card=1, ckpt="n12c1_ckpt78.npz"),
     "n12c12": dict(n=12, card=12, ckpt=None),
+    "n37c37": dict(n=37, card=37, ckpt=None),      # alarm-size (BASELINE config 5); slim fixture: no train-mode grads
 }
 
 

@@ -37,7 +37,13 @@ def test_host_side_queries_without_a_gpu():
     assert all(off % 4 == 0 for _, off, _ in table)
     assert sum(int(__import__("numpy").prod(s)) for _, _, s in table) == 310160       # n=12 card=12
     assert lib.dvs_workspace_bytes(ctypes.byref(shape)) > 0
-    bad = dl.make_shape(16, 40, 40)                                                     # alarm size: not in this build
+    assert dl.record_bytes(lib, shape) == 96
+    alarm = dl.make_shape(16, 40, 40)                                                   # alarm size: wide path
+    assert lib.dvs_param_count(ctypes.byref(alarm)) >= 470185                           # n=37 card=37
+    table40, _ = dl.param_table(lib, alarm)
+    assert sum(int(__import__("numpy").prod(s)) for _, _, s in table40) == 470185
+    assert dl.record_bytes(lib, alarm) == 864
+    bad = dl.make_shape(16, 49, 40)
     assert lib.dvs_param_count(ctypes.byref(bad)) < 0
     assert b"n_tokens" in lib.dvs_last_error()
 

@@ -26,10 +26,12 @@ def _check_grads(got, ref, tol):
         assert err < tol, (k, err)
 
 
-@pytest.mark.parametrize("name,B", [("n12c12", 5), ("asia_rand", 6), ("n12c1", 3)])
+@pytest.mark.parametrize("name,B", [("n12c12", 5), ("asia_rand", 6), ("n12c1", 3), ("n37c37", -4)])
 def test_emu_gradients_eval(name, B):
     cfg, params, graphs, z = load_golden(name)
-    f_np = ofeat.dense_features(graphs[:B], cfg.card)
+    graphs = graphs[:B] if B > 0 else graphs[B:]
+    B = len(graphs)
+    f_np = ofeat.dense_features(graphs, cfg.card)
     m = EmuModel(cfg, {k: v.numpy() for k, v in params.items()}, B, training=False)
     assert m.pack(f_np) == 0
     m.forward()
@@ -39,7 +41,7 @@ def test_emu_gradients_eval(name, B):
     _check_grads(grads, ref, 1e-3)
 
 
-@pytest.mark.parametrize("name,B,seed", [("n12c12", 6, 1234), ("asia_rand", 4, 99)])
+@pytest.mark.parametrize("name,B,seed", [("n12c12", 6, 1234), ("asia_rand", 4, 99), ("n37c37", 3, 4321)])
 def test_emu_train_mode_with_dropout_and_hashed_eps(name, B, seed):
     """dropout 0.15 + counter-based eps: the oracle runs with the device's masks (oracle/rng.py)."""
     cfg, params, graphs, z = load_golden(name)

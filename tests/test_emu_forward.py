@@ -9,11 +9,12 @@ from tests.emu.harness import EmuModel
 from tests.helpers import load_golden, rel
 
 
-@pytest.mark.parametrize("name,B", [("n12c12", 6), ("asia_rand", 5), ("n12c1", 4)])
+@pytest.mark.parametrize("name,B", [("n12c12", 6), ("asia_rand", 5), ("n12c1", 4), ("n37c37", -5)])
 def test_emu_forward_eval_matches_oracle(name, B):
     cfg, params, graphs, z = load_golden(name)
-    graphs = graphs[:B]
+    graphs = graphs[:B] if B > 0 else graphs[B:]          # n37c37: the last ones are the chain / star DAGs
     f_np = ofeat.dense_features(graphs, cfg.card)
+    B = len(graphs)
     m = EmuModel(cfg, {k: v.numpy() for k, v in params.items()}, B, training=False)
     assert m.pack(f_np) == 0
     losses, mu, lv = m.forward()
@@ -29,19 +30,21 @@ def test_emu_forward_eval_matches_oracle(name, B):
     assert losses[3] == 0.0
 
 
-@pytest.mark.parametrize("n,card,seed", [(12, 12, 3), (8, 8, 4), (11, 11, 5), (5, 2, 6)])
+@pytest.mark.parametrize("n,card,seed", [(12, 12, 3), (8, 8, 4), (11, 11, 5), (5, 2, 6), (37, 37, 7), (20, 3, 8), (45, 45, 9)])
 def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     """Device-side front-end (dvs_build_records) == dvs_pack_features(oracle dense features), byte for byte."""
     import ctypes
     from dags_vae_search_amd import _lib as dl
     from dags_vae_search_amd.records import encode_graphs
     from tests.emu.harness import emu, ptr
-    graphs = ofeat.synthetic_dags(n, card, 96, seed=seed)
+    graphs = ofeat.synthetic_dags(n, card, 96 if n <= 13 else 24, seed=seed, density_limit=0.4 if n <= 13 else 0.2)
     B = len(graphs)
     lib = emu()
     shape = dl.make_shape(B, n + 3, card + 3)
     f = ofeat.dense_features(graphs, card)
-    rec_a = np.zeros(B * dl.RECORD_BYTES, np.uint8)
+    RB = dl.record_bytes(lib, shape)
+    assert RB == (96 if n <= 13 else 864)
+    rec_a = np.zeros(B * RB, np.uint8)
     status = np.zeros(1, np.int32)
     tm = np.ascontiguousarray(f["target_masks"]).astype(np.uint8)
     assert lib.dvs_pack_features(ctypes.byref(shape), ptr(f["vertex_label_features"]), ptr(f["vertex_position_features"]),
@@ -50,15 +53,30 @@ def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     cb = encode_graphs(graphs, n)
     lab = np.ascontiguousarray(cb.labels.numpy())
     pr = np.ascontiguousarray(cb.preds.numpy())
-    rec_b = np.zeros(B * dl.RECORD_BYTES, np.uint8)
+    rec_b = np.zeros(B * RB, np.uint8)
     assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab), ptr(pr), ptr(rec_b), ptr(status), None) == 0
     assert status[0] == 0
     assert np.array_equal(rec_a, rec_b)
     # non-identity positions occur (the order quirk is exercised)
-    pos = rec_b.reshape(B, 96)[:, 16:16 + n + 3]
+    pos = rec_b.reshape(B, RB)[:, 16:16 + n + 3] if n <= 13 else rec_b.reshape(B, RB)[:, 48:48 + n + 3]
     assert (pos != np.arange(n + 3)).any() or n < 6
     # bad label -> status bit 0
     lab2 = lab.copy()
     lab2[0, 0] = card + 5
     assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab2), ptr(pr), ptr(rec_b), ptr(status), None) == 0
     assert status[0] & 1
+
+
+def test_emu_wide_forward_matches_reference_golden():
+    """Alarm-size (n = 37, BASELINE config 5) on the tiled wide path: the whole 16-DAG fixture (random DAGs at density
+    <= 0.2, a 37-level chain, a chain with skips, a star, a 36-parent sink) against the reference's own outputs."""
+    cfg, params, graphs, z = load_golden("n37c37")
+    f_np = ofeat.dense_features(graphs, cfg.card)
+    m = EmuModel(cfg, {k: v.numpy() for k, v in params.items()}, len(graphs), training=False)
+    assert m.pack(f_np) == 0
+    losses, mu, lv = m.forward()
+    assert rel(losses[0], z["eval/total"]) < 1e-4 and rel(losses[1], z["eval/recon"]) < 1e-4
+    assert rel(losses[2], z["eval/kld"]) < 1e-5
+    assert np.abs(mu - z["eval/mu"]).max() < 2e-5 and np.abs(lv - z["eval/logvar"]).max() < 2e-5
+    dec = m.activation(16)          # last decoder sublayer's pre-LayerNorm sum: [B, 48, 64]
+    assert dec.shape == (len(graphs), 48, 64) and np.isfinite(dec).all() and np.abs(dec[:, 40:]).max() == 0.0

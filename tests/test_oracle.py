@@ -82,6 +82,8 @@ def test_oracle_matches_reference_train0_and_step(name):
     value, recon, kld = tr.step(f, training=True, eps=torch.from_numpy(z["train0/eps"]))
     assert rel(value, z["train0/total"]) < 1e-5
     assert rel(kld, z["train0/kld"]) < 1e-5
+    if not any(k.startswith("step/param/") for k in z.files):
+        return          # slim fixture (n37c37): losses only
     # First Adam step moves each weight by lr*g/(|g|+1e-8): well-conditioned only where the clipped
     # gradient is >> 1e-8, so compare tightly there and loosely (a fraction of one lr step) elsewhere.
     gn = np.sqrt(sum(float((z[k].astype(np.float64) ** 2).sum()) for k in z.files if k.startswith("train0/grad/")))

@@ -27,7 +27,14 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-N_VERT, CARD = 12, 12
+N_VERT, CARD = 12, 12            # --workload changes these (the driver's default run is the BASELINE metric shape)
+WORKLOADS = {   # name: (n, card, default per-GPU batch, edge-density limit, description)
+    "n12": (12, 12, 4096, 0.4, "synthetic_v12 DAGs (n=12, card=12, N=15 tokens)"),
+    "asia": (8, 8, 4096, 0.4, "asia-shaped synthetic DAGs (n=8, card=8, N=11 tokens)"),
+    "sachs": (11, 11, 8192, 0.4, "sachs-shaped synthetic DAGs (n=11, card=11, N=14 tokens)"),
+    "alarm": (37, 37, 2048, 0.2, "alarm-size synthetic DAGs (n=37, card=37, N=40 tokens, tiled wide path)"),
+}
+DENSITY = 0.4
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix/vector peak
 PEAK_HBM_GBS = 8000.0
 
@@ -77,7 +84,7 @@ def pmc_traffic_bytes(kernel: str, batch: int):
 def make_batch(batch: int, seed: int, device):
     from dags_vae_search_amd import prepare_features
     from dags_vae_search_amd.synthetic import synthetic_dags
-    graphs = synthetic_dags(N_VERT, CARD, batch, seed=seed)
+    graphs = synthetic_dags(N_VERT, CARD, batch, seed=seed, density_limit=DENSITY)
     feats = prepare_features(graphs, N_VERT + 3, CARD + 3)
     dev_feats = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in feats.items()}
     return graphs, feats, dev_feats
@@ -129,11 +136,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="DAGs per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="DAGs per GPU (default: the workload's)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="n12",
+                    help="n12 = the BASELINE metric shape (default); the others are the remaining BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the RCCL code path even with one rank (checks init / all-reduce plumbing on a 1-GPU box)")
     args = ap.parse_args()
+    global N_VERT, CARD, DENSITY
+    N_VERT, CARD, default_batch, DENSITY, workload_desc = WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = default_batch
 
     # libraries (RCCL's version banner, ...) write to fd 1: keep stdout clean for the ONE JSON line
     sys.stdout.flush()
@@ -214,23 +227,25 @@ def main():
         kern = {k: {"launches_per_step": c // prof_steps, "avg_us": 1e3 * ms / c, "ms_per_step": ms / prof_steps}
                 for k, (c, ms) in prof.items()}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        ach = flops.get(dom, 0.0) * args.batch / (kern[dom]["avg_us"] * 1e-6) / 1e12
-        step_flops = 3 * 8.46e6 if (N_VERT, CARD) == (12, 12) else sum(flops.values())
+        dom_key = dom[:-2] if dom.endswith("_w") else dom          # wide-path kernels: same algorithmic work
+        ach = flops.get(dom_key, 0.0) * args.batch / (kern[dom]["avg_us"] * 1e-6) / 1e12
+        step_flops = 3e6 * {8: 5.71, 11: 7.74, 12: 8.46, 37: 34.0}[N_VERT]      # 3 x forward MFLOP per DAG
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(dom, args.batch),
                     "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
-                    "algorithmic_flops_per_dag": flops.get(dom, 0.0),
+                    "algorithmic_flops_per_dag": flops.get(dom_key, 0.0),
                     "whole_step": {"tflops": value / world * step_flops / 1e12,
                                    "frac_f32_mfma_peak": value / world * step_flops / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                    "hbm_algorithmic_GBs": value / world * bytes_per_dag(N, C, P, args.batch) / 1e9,
                                    "frac_hbm_peak": value / world * bytes_per_dag(N, C, P, args.batch) / 1e9 / PEAK_HBM_GBS,
                                    "gpu_kernel_ms_per_step": sum(k["ms_per_step"] for k in kern.values())}}
         out = {
-            "metric": "DAGs/sec VAE+predictor train step, n=12 batch 4096",
+            "metric": "DAGs/sec VAE+predictor train step, n=12 batch 4096" if args.workload == "n12" else
+                      f"DAGs/sec VAE+predictor train step, n={N_VERT} batch {args.batch}",
             "value": value, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic_v12 DAGs (n=12, card=12, N=15 tokens), PACE-VAE train step: pack + fwd + bwd"
+            "config": {"workload": workload_desc + ", PACE-VAE train step: pack + fwd + bwd"
                                    " + clip_grad_norm_(1.0) + Adam(1e-4), train mode dropout 0.15",
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}" if world > 1 else "single",

@@ -131,7 +131,7 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):
         cpu_model.loss_direct({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()})
     with pytest.raises(NotImplementedError):
-        PaceVaeV3(37, 37, 32, 8, 3, 64, 32, 32, 0.15)
+        PaceVaeV3(46, 46, 32, 8, 3, 64, 32, 32, 0.15)      # > 48 tokens
     with pytest.raises(NotImplementedError):
         PaceVaeV3(8, 8)                      # reference defaults (256-wide, 6 layers) are not this build
 
@@ -249,3 +249,120 @@ def test_compact_batch_front_end_equals_dense_features_path():
         for batch in ds.batches(256, generator=torch.Generator().manual_seed(epoch)):
             losses.append(train_batch(batch, model, opt)[0] / len(batch))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def _alarm_graphs(count, seed):
+    """BASELINE config 5 inputs: n = 37 synthetic DAGs at density <= 0.2 plus deep chains (irregular, 37-level orders)."""
+    from dags_vae_search_amd import LabeledGraph
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    n = 37
+    graphs = synthetic_dags(n, n, count - 8, seed=seed, density_limit=0.2)
+    rng = np.random.default_rng(seed + 1)
+    chain = [(v, v + 1) for v in range(n - 1)]
+    for k in range(8):
+        extra = [(v, v + 2 + k) for v in range(0, n - 2 - k, 3)]
+        graphs.append(LabeledGraph([int(x) for x in rng.permutation(n)], sorted(set(chain + (extra if k else [])))))
+    return graphs
+
+
+def test_alarm_n37_b2048_wide_path():
+    """BASELINE config 5 (alarm-size n = 37, batch 2048, one MI355X), tiled wide path: ELBO vs the CPU oracle on the
+    identical batch < 1e-4 relative (eval), dropout-on gradients vs the oracle run with the device's masks on a
+    sub-batch, bitwise determinism, shard additivity, compact front-end == dense features, and loss-reducing steps."""
+    from dags_vae_search_amd import encode_graphs, optim as dopt
+    from dags_vae_search_amd.dist import shard_features
+    from dags_vae_search_amd.train import train_batch
+    cfg = po.PaceConfig(n=37, card=37)
+    params = po.init_params(cfg, seed=8)
+    graphs = _alarm_graphs(2048, seed=31)
+    model = build_model(cfg, params)
+    f = model.prepare_features(graphs)
+    f_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()}
+    model.eval()
+    total, recon, kld = model.loss_direct(f)
+    with torch.no_grad():
+        t, r, k = po.loss_direct(params, cfg, f_cpu, training=False)
+    assert rel(total.item(), t) < 1e-4 and rel(recon.item(), r) < 1e-4 and rel(kld.item(), k) < 1e-4
+    # device-side front-end (64-bit rows) gives the same records
+    cb = encode_graphs(graphs, 37).to(DEV)
+    assert [x.item() for x in model.loss_direct(cb)] == [total.item(), recon.item(), kld.item()]
+    # dropout-on gradients on the last 24 DAGs (they include the chains)
+    sub = graphs[-24:]
+    fs = model.prepare_features(sub)
+    model.train()
+    model.seed(9)
+    model.dag_offset = 3
+    tt, rr, kk = model.loss_direct(fs)
+    tt.backward()
+    masks = DeviceMasks((9 << 32) | 1, 0.15, dag_offset=3)
+    P = {k2: v.clone().requires_grad_(True) for k2, v in params.items()}
+    fs_cpu = {k2: (v.cpu() if torch.is_tensor(v) else v) for k2, v in fs.items()}
+    to, ro, ko = po.loss_direct(P, cfg, fs_cpu, training=True, eps=torch.from_numpy(masks.eps(24)), masks=masks)
+    to.backward()
+    assert rel(tt.item(), to.detach()) < 1e-4 and rel(kk.item(), ko.detach()) < 1e-4
+    scale = max(float(p.grad.abs().max()) for p in P.values())
+    for name, p in model.named_parameters():
+        ref = P[name].grad.numpy()
+        e = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale)
+        assert e < 3e-3, (name, e)
+    model.dag_offset = 0
+    model.zero_grad(set_to_none=True)
+    # full-size properties
+    model.seed(1)
+    l1 = model.loss_and_grad(f).clone()
+    g1 = model.flat_grads.clone()
+    model.seed(1)
+    l2 = model.loss_and_grad(f).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, model.flat_grads)
+    tot = torch.zeros_like(g1)
+    lsum = 0.0
+    for rank in range(2):
+        shard, off = shard_features(f, rank, 2)
+        model.seed(1)
+        model.dag_offset = off
+        ls = model.loss_and_grad(shard)
+        tot += model.flat_grads
+        lsum += ls[0].item()
+    model.dag_offset = 0
+    assert rel(lsum, l1[0].item()) < 1e-5
+    assert (tot - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
+    opt = dopt.Adam(model.parameters(), lr=1e-3).attach(model)
+    first = None
+    for step in range(8):
+        loss_value, _, _ = train_batch(f, model, opt)
+        first = loss_value if first is None else first
+    assert np.isfinite(loss_value) and loss_value < 0.97 * first
+
+
+@pytest.mark.parametrize("n,B", [(12, 8192), (11, 8192)])
+def test_batch_8192_per_gpu_shapes(n, B):
+    """BASELINE configs 3 (n = 12, batch 8192 on one GPU) and 4 (sachs n = 11, 65 536 over 8 GPUs = 8192 per GPU):
+    ELBO of the full batch vs the CPU oracle on a 512-DAG slice summed with the rest via shard additivity, and
+    run-to-run determinism at the full size."""
+    from dags_vae_search_amd.dist import shard_features
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    cfg = po.PaceConfig(n=n, card=n)
+    params = po.init_params(cfg, seed=n)
+    graphs = synthetic_dags(n, n, B, seed=100 + n)
+    model = build_model(cfg, params).eval()
+    f = model.prepare_features(graphs)
+    full = [x.item() for x in model.loss_direct(f)]
+    parts = [0.0, 0.0, 0.0]
+    for rank in range(16):
+        shard, off = shard_features(f, rank, 16)
+        model.dag_offset = off
+        got = [x.item() for x in model.loss_direct(shard)]
+        if rank == 5:       # one 512-DAG shard against the CPU path
+            with torch.no_grad():
+                t, r, k = po.loss_direct(params, cfg, {k2: (v.cpu() if torch.is_tensor(v) else v) for k2, v in shard.items()})
+            assert rel(got[0], t) < 1e-4 and rel(got[2], k) < 1e-4
+        parts = [a + b for a, b in zip(parts, got)]
+    model.dag_offset = 0
+    assert all(rel(a, b) < 1e-5 for a, b in zip(parts, full))
+    model.train()
+    model.seed(4)
+    l1 = model.loss_and_grad(f).clone()
+    g1 = model.flat_grads.clone()
+    model.seed(4)
+    l2 = model.loss_and_grad(f)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.flat_grads)

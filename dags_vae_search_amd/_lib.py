@@ -16,6 +16,7 @@ LIB_NAME = "libdvs_hip.so"
 D_MODEL, HEADS, LAYERS, LATENT, FC_HIDDEN, EMB = 64, 8, 3, 32, 32, 32
 MAX_TOKENS = 48           # 16 on the one-tile path (a wavefront owns a DAG); up to 48 on the tiled wide path
 TILE_TOKENS = 16
+DECODE_STATE_BYTES = 440
 RECORD_BYTES = 96         # one-tile path; record_bytes(lib, shape) gives the size that applies
 
 
@@ -54,6 +55,8 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_encode.restype = c_int
     lib.dvs_encode.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_decode.restype = c_int
+    lib.dvs_decode.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_clip_adam.restype = c_int
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_int64, c_float, c_void_p, c_void_p]
@@ -67,7 +70,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode",
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
 
 

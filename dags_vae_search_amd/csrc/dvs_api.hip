@@ -466,38 +466,9 @@ LossArgs dvs_loss_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace&
     return a;
 }
 
-extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
-                                const float* eps, float* losses, float* mu, float* logvar, void* stream) {
-    if (int e = check_shape(s)) return e;
-    if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
-    const DvsDims d = make_dims(s);
-    const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
-    float* ws = (float*)workspace;
-    const DvsRecord* rec = (const DvsRecord*)records;
-    dvs_stream_t st = (dvs_stream_t)stream;
-    const FwdGrids grid = fwd_grids(d, is_wide(s));
-
-    encoder_forward(d, L, W, rec, params, ws, grid, st);
-    dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
-
-    // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
-    // only to redraw the dropout masks)
-    int dec_in = 0;
-    if (d.drop.on) {
-        EmbedArgs e;
-        memset(&e, 0, sizeof(e));
-        e.dims = d;
-        e.rec = rec;
-        e.W1 = params + L.W1;
-        e.W2 = params + L.W2;
-        e.lab_w = params + L.lab_w;
-        e.lab_b = params + L.lab_b;
-        e.out = ws + W.act[7];
-        e.site = 2;
-        launch_embed_fwd(e, grid, st);
-        dec_in = 7;
-    }
+// TransformerDecoder forward (pace.py:163-182) from the embedding in slot `dec_in`; memory = W.mem.
+static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
+                            const float* params, float* ws, const FwdGrids& grid, int dec_in, dvs_stream_t st) {
     DvsLN ln = {nullptr, nullptr, nullptr};
     int prev = dec_in;
     for (int i = 0; i < DVS_LAYERS; ++i) {
@@ -555,6 +526,41 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
         ln = DvsLN{ws + W.stats[s2], params + pl.n3.w, params + pl.n3.b};
         prev = s2;
     }
+}
+
+extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
+                                const float* eps, float* losses, float* mu, float* logvar, void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
+    const DvsDims d = make_dims(s);
+    const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
+    float* ws = (float*)workspace;
+    const DvsRecord* rec = (const DvsRecord*)records;
+    dvs_stream_t st = (dvs_stream_t)stream;
+    const FwdGrids grid = fwd_grids(d, is_wide(s));
+
+    encoder_forward(d, L, W, rec, params, ws, grid, st);
+    dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
+
+    // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
+    // only to redraw the dropout masks)
+    int dec_in = 0;
+    if (d.drop.on) {
+        EmbedArgs e;
+        memset(&e, 0, sizeof(e));
+        e.dims = d;
+        e.rec = rec;
+        e.W1 = params + L.W1;
+        e.W2 = params + L.W2;
+        e.lab_w = params + L.lab_w;
+        e.lab_b = params + L.lab_b;
+        e.out = ws + W.act[7];
+        e.site = 2;
+        launch_embed_fwd(e, grid, st);
+        dec_in = 7;
+    }
+    decoder_forward(d, L, W, rec, params, ws, grid, dec_in, st);
     if (grid.wide) dvs_launch_loss_fwd_w(dvs_loss_args(d, L, W, rec, params, ws), grid.dags, st);
     else dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.tiles8, st);
     FinalizeArgs fa;
@@ -595,6 +601,62 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* 
     (void)hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st);
 #endif
+    return 0;
+}
+
+// ---- generation (k_decode.hip) -------------------------------------------------------------------------------------
+#include "dvs_decode.h"
+
+extern "C" int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* records, const float* z,
+                          const float* uniforms, void* state_out, void* stream) {
+    if (int e = check_shape(s)) return e;
+    if (!params || !workspace || !records || !z || !state_out) return fail(10, "dvs_decode: null pointer");
+    if (s->training) return fail(13, "dvs_decode: generation runs in eval mode (shape.training must be 0)");
+    const DvsDims d = make_dims(s);
+    const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
+    float* ws = (float*)workspace;
+    dvs_stream_t st = (dvs_stream_t)stream;
+    const bool wide = is_wide(s);
+    const FwdGrids grid = fwd_grids(d, wide);
+    const DvsRecord* rec = (const DvsRecord*)records;
+
+    dvs_launch_decode_memory(d, z, params + L.fc3_w, params + L.fc3_b, ws + W.mem, st);
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dims = d;
+    a.wide = wide ? 1 : 0;
+    a.rec = records;
+    a.state = (DvsDecodeState*)state_out;
+    const int last = slot_dec(DVS_LAYERS - 1, 2);
+    a.xin = ws + W.act[last];
+    a.ln = DvsLN{ws + W.stats[last], params + L.dec[DVS_LAYERS - 1].n3.w, params + L.dec[DVS_LAYERS - 1].n3.b};
+    a.node0_w = params + L.node0_w;
+    a.node0_b = params + L.node0_b;
+    a.node2_w = params + L.node2_w;
+    a.node2_b = params + L.node2_b;
+    a.edge0_w = params + L.edge0_w;
+    a.edge0_b = params + L.edge0_b;
+    a.edge2_w = params + L.edge2_w;
+    a.edge2_b = params + L.edge2_b;
+    a.uniforms = uniforms;
+    dvs_launch_decode_init(a, st);
+    for (int idx = 2; idx < d.N; ++idx) {
+        EmbedArgs e;
+        memset(&e, 0, sizeof(e));
+        e.dims = d;
+        e.rec = rec;
+        e.W1 = params + L.W1;
+        e.W2 = params + L.W2;
+        e.lab_w = params + L.lab_w;
+        e.lab_b = params + L.lab_b;
+        e.out = ws + W.act[7];
+        e.site = 2;
+        launch_embed_fwd(e, grid, st);
+        decoder_forward(d, L, W, rec, params, ws, grid, 7, st);
+        a.idx = idx;
+        dvs_launch_decode_step(a, grid_for(d.B, 4), st);
+    }
     return 0;
 }
 

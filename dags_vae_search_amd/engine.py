@@ -138,6 +138,18 @@ class PaceEngine:
         dl.check(self.lib, self.lib.dvs_encode(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
                                                _ptr(mu), _ptr(logvar), _stream()), "dvs_encode")
 
+    def decode(self, shape, params: torch.Tensor, z: torch.Tensor, uniforms: Optional[torch.Tensor]) -> torch.Tensor:
+        """dvs_decode: the whole autoregressive generation loop on the device.  Returns the raw dvs_decode_state
+        records as a uint8 tensor [B, DECODE_STATE_BYTES]."""
+        _require_cuda(params, "parameters")
+        _require_cuda(z, "z")
+        B = z.shape[0]
+        ws = self.workspace(B, params.device)
+        state = torch.empty(B, dl.DECODE_STATE_BYTES, dtype=torch.uint8, device=params.device)
+        dl.check(self.lib, self.lib.dvs_decode(ctypes.byref(shape), _ptr(params), _ptr(ws), _ptr(self._records), _ptr(z),
+                                               _ptr(uniforms), _ptr(state), _stream()), "dvs_decode")
+        return state
+
     def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch):
         dl.check(self.lib, self.lib.dvs_clip_adam(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg),
                                                   _ptr(exp_avg_sq), lr, beta1, beta2, eps, int(step), float(max_norm),

@@ -10,7 +10,8 @@ Differences a user can observe:
     workgroup-per-DAG kernels) — anything else raises NotImplementedError;
   * dropout masks / reparameterisation noise come from a counter-based generator keyed by (seed, step, DAG index)
     instead of torch's global generator (``model.seed(s)`` re-seeds it; ``eps=`` injects the noise);
-  * ``decode`` (generation, pace.py:1666-1749) is outside this path and raises NotImplementedError.
+  * ``decode`` (generation, pace.py:1666-1749) runs batched on the device and returns LabeledGraph objects; its
+    random draws are the model's own counter-based ones (or injected ``uniforms``), see decode().
 All 108 parameters are views into ONE flat fp32 buffer (``model.flat_params``) and their gradients views into
 ``model.flat_grads``: one RCCL all-reduce and one fused clip+Adam kernel cover the whole model.
 """
@@ -305,9 +306,50 @@ class PaceVaeV3(nn.Module):
             return mu + torch.randn_like(std) * epsilon_scale * std
         return mu
 
-    def decode(self, z: torch.Tensor):
-        raise NotImplementedError("decode() (sequential generation, pace.py:1666-1749) is not on the train-step hot "
-                                  "path built in this round (SURVEY.md §8f item 2)")
+    def decode(self, z: torch.Tensor, uniforms: Optional[torch.Tensor] = None, strict: bool = True):
+        """Generation (pace.py:1666-1749), batched on the device: returns one LabeledGraph per row of ``z``.
+
+        The reference grows igraph objects on the host and samples with numpy's / torch's global generators; here the
+        N-2 step loop runs in HIP (csrc/k_decode.hip) and draws from the model's counter-based generator
+        (``model.seed``), or from ``uniforms`` ([B, N, N], see include/dvs.h) when given.  Quirks kept: no start->input
+        edge in the grown graph, the last vertex is hooked to the loose ends only if its SAMPLED type was `output`,
+        edges into the first user vertex are dropped by the PACE -> labelled conversion (pace.py:1298).  A graph that
+        samples `output` early stops growing; the reference then fails with IndexError inside
+        from_pace_graph_to_labeled_graph — so does this (``strict=True``); ``strict=False`` returns None for those."""
+        import numpy as np
+        eng = self._eng()
+        dev = self.flat_params.device
+        z = z.to(dev, torch.float32).contiguous()
+        B = z.shape[0]
+        if z.dim() != 2 or z.shape[1] != self.latent_layer_size:
+            raise AssertionError(f"Expected z of shape [B, {self.latent_layer_size}], got {tuple(z.shape)}")
+        N = self._max_num_vertices
+        if uniforms is not None:
+            uniforms = uniforms.to(dev, torch.float32).contiguous()
+            if tuple(uniforms.shape) != (B, N, N):
+                raise AssertionError(f"Expected uniforms of shape [{B}, {N}, {N}], got {tuple(uniforms.shape)}")
+        self._step += 1
+        shape = eng.shape(B, training=False, dropout=self.dropout, dag_offset=self.dag_offset,
+                          seed=(self._seed << 32) | (self._step & 0xFFFFFFFF))
+        raw = eng.decode(shape, self.flat_params, z, uniforms).cpu().numpy()
+        self._fwd_generation += 1
+        parents = raw[:, :384].copy().view(np.uint64)            # [B, 48]
+        labels = raw[:, 384:432]
+        nv = raw[:, 432:436].copy().view(np.int32)[:, 0]
+        out = []
+        for b in range(B):
+            if nv[b] < N:
+                if strict:
+                    raise IndexError("vertex index out of range")    # igraph's error at pace.py:1296
+                out.append(None)
+                continue
+            lab = [int(labels[b, v]) - 3 for v in range(2, N - 1)]
+            edges = []
+            for v in range(3, N - 1):                                # v == 2 is skipped (pace.py:1298)
+                row = int(parents[b, v])
+                edges.extend((u - 2, v - 2) for u in range(2, v) if (row >> u) & 1)
+            out.append(feat.LabeledGraph(lab, edges))
+        return out
 
     # ---- loss (pace.py:1974-2046) -------------------------------------------------------------------------------
     def loss_direct(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None):

@@ -33,6 +33,7 @@ extern "C" {
 #define DVS_RECORD_BYTES 96          /* one-tile path */
 #define DVS_RECORD_BYTES_WIDE 864    /* wide path; dvs_record_bytes(shape) returns the one that applies */
 #define DVS_CLIP_SCRATCH_FLOATS 320
+#define DVS_DECODE_STATE_BYTES 440   /* sizeof(dvs_decode_state) */
 
 typedef struct dvs_shape {
     int32_t batch;        /* DAGs in this (rank-local) batch */
@@ -107,6 +108,24 @@ int dvs_encode(const dvs_shape* s, const void* records, const float* params, voi
 int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
                   void* stream);
+
+/* One grown PACE graph of dvs_decode (vertex 0 = start, 1 = input, then the sampled vertices in order). */
+typedef struct dvs_decode_state {
+    uint64_t parents[48];   /* bit j of parents[i]: edge j -> i */
+    uint8_t label[48];      /* PACE label of vertex i (user label + 3; 0 input, 1 output, 2 start) */
+    int32_t nv;             /* number of vertices; == n_tokens unless the graph sampled `output` early */
+    int32_t finished;       /* 1: the graph sampled `output` and stopped growing (pace.py:1738-1743) */
+} dvs_decode_state;
+
+/* PaceVaeV3.decode (pace.py:1666-1749), batched on the device.  z: device [B,32] latents;
+ * records: device scratch of batch * dvs_record_bytes bytes; state_out: device dvs_decode_state[B].  The whole
+ * n_tokens - 2 step autoregressive loop (records of the partial graphs -> embedding -> 3 decoder layers -> node-type /
+ * edge sampling -> graph update) is enqueued on `stream`; nothing is read back in between.  uniforms: optional device
+ * f32 [B, n_tokens, n_tokens]; step idx uses [b, idx, 0] for the node type (inverse CDF, as np.random.choice) and
+ * [b, idx, 1 + vi] for edge candidate vi (edge iff u < sigmoid score, as torch.rand_like < score); NULL = counter-based
+ * draws from s->seed.  s->training must be 0 (the reference decodes in eval mode). */
+int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* records, const float* z,
+               const float* uniforms, void* state_out, void* stream);
 
 /* Optional per-kernel timing for the benchmark's roofline leg: while enabled, every kernel launch is bracketed by
  * HIP events recorded on its own stream; dvs_profile_collect waits for them and returns, per kernel name, the

@@ -1,0 +1,71 @@
+"""Batched generation (dvs_decode) on the host emulator vs the oracle restatement of PaceVaeV3.decode
+(oracle/decode.py) with the SAME injected uniforms: identical grown graphs, vertex by vertex and edge by edge."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dags_vae_search_amd import _lib as dl
+from oracle import decode as odec
+from oracle import features as ofeat
+from oracle import pace_oracle as po
+from tests.emu.harness import emu, ptr
+from tests.helpers import load_golden
+
+
+def parse_states(raw, B):
+    st = np.ascontiguousarray(raw).reshape(B, dl.DECODE_STATE_BYTES)
+    out = []
+    for b in range(B):
+        par = st[b, :384].copy().view(np.uint64)
+        nv, fin = (int(x) for x in st[b, 432:440].copy().view(np.int32))
+        edges = sorted((j, i) for i in range(nv) for j in range(48) if (int(par[i]) >> j) & 1)
+        out.append((nv, [int(x) for x in st[b, 384:384 + nv]], edges, bool(fin)))
+    return out
+
+
+@pytest.mark.parametrize("name,B,seed", [("asia", 8, 1), ("n12c12", 6, 2), ("n12c1", 4, 3), ("n37c37", 2, 4)])
+def test_emu_decode_equals_oracle_decode(name, B, seed):
+    cfg, params, graphs, z = load_golden(name)
+    lib = emu()
+    shape = dl.make_shape(B, cfg.N, cfg.C, False, 0.15, seed=5)
+    table, P = dl.param_table(lib, shape)
+    flat = np.zeros(P, np.float32)
+    for nm, off, shp in table:
+        v = params[nm].numpy().reshape(-1)
+        flat[off:off + v.size] = v
+    ws = np.zeros(lib.dvs_workspace_bytes(ctypes.byref(shape)) // 4 + 64, np.float32)
+    rec = np.zeros(B * dl.record_bytes(lib, shape), np.uint8)
+    state = np.zeros(B * dl.DECODE_STATE_BYTES, np.uint8)
+    rng = np.random.default_rng(seed)
+    zz = np.ascontiguousarray(z["eval/mu"][:B])
+    U = rng.random((B, cfg.N, cfg.N)).astype(np.float32)
+    assert lib.dvs_decode(ctypes.byref(shape), ptr(flat), ptr(ws), ptr(rec), ptr(zz), ptr(U), ptr(state), None) == 0
+    got = parse_states(state, B)
+    ref = odec.decode(params, cfg, torch.from_numpy(zz), U)
+    for (nv, lab, edges, fin), g in zip(got, ref):
+        assert nv == g.nv and lab == g.labels and edges == sorted(g.edges) and fin == g.finished
+    # training shapes are refused
+    bad = dl.make_shape(B, cfg.N, cfg.C, True, 0.15)
+    assert lib.dvs_decode(ctypes.byref(bad), ptr(flat), ptr(ws), ptr(rec), ptr(zz), ptr(U), ptr(state), None) != 0
+
+
+def test_oracle_decode_reproduces_the_published_asia_reconstruction():
+    """The shipped asia checkpoint reconstructs its test graphs: the reference reports valid 1.000 / exact 0.935 at epoch
+    100 (experiments/01_bn_asia/main.py:560); checkpoint 110 through the oracle's decode: every graph full-size and
+    >= 90 % exact on 96 decodes.  Pins the restated sampling semantics (edge direction, label shift, type <-> position
+    alignment): any slip there drops exact reconstruction to ~0."""
+    cfg, params, graphs, z = load_golden("asia")
+    with torch.no_grad():
+        mu, _ = po.encode_direct(params, cfg, ofeat.to_torch(ofeat.dense_features(graphs, cfg.card)))
+    rng = np.random.default_rng(0)
+    tot = ok = full = 0
+    for _ in range(2):
+        U = rng.random((len(graphs), cfg.N, cfg.N)).astype(np.float32)
+        for g, (lab, edges) in zip(odec.decode(params, cfg, mu, U), graphs):
+            r = odec.to_labeled(g, cfg.N)
+            tot += 1
+            full += r is not None
+            ok += r is not None and r[0] == list(lab) and sorted(r[1]) == sorted(edges)
+    assert full == tot and ok >= 0.9 * tot

@@ -8,3 +8,4 @@ from .pace import PaceVaeV3  # noqa: F401
 from .train import load_model_state, train_batch, train_model  # noqa: F401
 from . import optim  # noqa: F401
 from .records import CompactBatch, CompactDagDataset, encode_graphs  # noqa: F401
+from .bic import BNLearnWrapper  # noqa: F401

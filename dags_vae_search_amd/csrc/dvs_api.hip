@@ -660,6 +660,16 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, void* workspa
     return 0;
 }
 
+extern "C" int dvs_bic_scores_impl(int B, int n, int S, const uint64_t* data, const uint8_t* card, const uint64_t* parents,
+                                   double* local, double* out, int* status, void* stream);
+extern "C" int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, const uint64_t* data, const uint8_t* card,
+                              const uint64_t* parents, double* scratch, double* out, int32_t* status, void* stream) {
+    if (batch <= 0 || n_samples <= 0) return fail(2, "dvs_bic_scores: batch and n_samples must be > 0");
+    if (n_vars < 1 || n_vars > DVS_WTOK) return fail(3, "dvs_bic_scores: n_vars must be in [1, 48]");
+    if (!data || !card || !parents || !scratch || !out || !status) return fail(10, "dvs_bic_scores: null pointer");
+    return dvs_bic_scores_impl(batch, n_vars, n_samples, data, card, parents, scratch, out, status, stream);
+}
+
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
     if (int e = check_shape(s)) return e;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;

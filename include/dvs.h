@@ -127,6 +127,17 @@ typedef struct dvs_decode_state {
 int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* records, const float* z,
                const float* uniforms, void* state_out, void* stream);
 
+/* BIC of B discrete Bayesian-network structures on one data set (replaces BNLearnWrapper.score,
+ * src/problem/bn/bnlearn.py:27-61 = `Rscript bnlearn_score.R`: bnlearn::score(net, data, type = "bic")).
+ * data: device u64 [n_samples][ceil(n_vars/16)], variable i's level code (0..15) in bits 4*(i%16).. of word i/16;
+ * card: device u8 [n_vars] level counts; parents: device u64 [B][n_vars], bit u of parents[b][v] <=> edge u -> v in
+ * DATASET variable indices (bnlearn.py:40-45 maps graph vertex v to variable labels[v]); scratch: device f64
+ * [B][n_vars]; out: device f64 [B].  Tables of up to 36 864 (configuration, level) cells are counted densely in LDS;
+ * larger parent sets go through an LDS sort of the samples, which needs n_samples <= 16 384 and <= 63 key bits —
+ * otherwise bit 4 of status (device int32, zeroed by the caller) is set and that DAG's score is NaN.  n_vars <= 48. */
+int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, const uint64_t* data, const uint8_t* card,
+                   const uint64_t* parents, double* scratch, double* out, int32_t* status, void* stream);
+
 /* Optional per-kernel timing for the benchmark's roofline leg: while enabled, every kernel launch is bracketed by
  * HIP events recorded on its own stream; dvs_profile_collect waits for them and returns, per kernel name, the
  * number of launches and their summed duration in milliseconds (rows of `name_stride` chars).  Process-global

@@ -14,6 +14,7 @@ Fixtures written (data only — inputs and expected outputs):
   asia_known_answer.npz   256 rows of experiments/01_bn_asia/data/test/part.0.parquet (labels + edge
                           strings) matched to their ``mu`` vectors in predictor_dataset/part-*.parquet
                           (written by the reference's prepare_predictor_data, main.py:268-303)
+  bn_{asia,sachs}_data.npz  the discrete data sets behind the BIC scorer (data/bn_*/target.csv), level-coded u8
   golden_<cfg>.npz        for cfg in {asia, asia_rand (synthetic n=8 graphs, ckpt 110), n12c1, n12c12 and n37c37
                           (alarm-size; fresh-seed parameters, stored under param/; n37c37 is 'slim')}: graphs -> reference outputs: eval-mode
                           (total, recon, kld, mu, logvar, decoder_output) + all gradients; train-mode
@@ -192,6 +193,23 @@ def main():
     golden(PaceVaeV3, "n12c1", 12, 1, sd_n12, ofeat.synthetic_dags(12, 1, 48, seed=11), seed=8)
     golden(PaceVaeV3, "n12c12", 12, 12, None, ofeat.synthetic_dags(12, 12, 48, seed=12), seed=9)
     golden(PaceVaeV3, "n37c37", 37, 37, None, alarm_graphs(), seed=10, slim=True)
+    bn_data()
+
+
+def bn_data():
+    """Level-coded copies of the reference's discrete data sets (data/bn_asia/target.csv, data/bn_sachs/target.csv:
+    5 000 samples each; levels coded by sorted name, which BIC does not depend on)."""
+    import csv
+    for name in ("asia", "sachs"):
+        rows = list(csv.reader(open(f"{REF}/data/bn_{name}/target.csv")))
+        names, rows = rows[0], rows[1:]
+        cols = []
+        for c in range(len(names)):
+            lv = sorted(set(r[c] for r in rows))
+            cols.append(np.array([lv.index(r[c]) for r in rows], np.uint8))
+        data = np.stack(cols, 1)
+        np.savez_compressed(os.path.join(HERE, f"bn_{name}_data.npz"), data=data, names=np.asarray(names))
+        print(f"bn_{name}_data: {data.shape}, levels {(data.max(0) + 1).tolist()}")
 
 
 def alarm_graphs():

@@ -38,7 +38,8 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
 }
 constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 2 * DVS_WTOK;
 
-__global__ __launch_bounds__(256) void k_attn_bwd_w(AttnBwdArgs a) {
+// 8 waves: waves 0..NT-1 own the tiles (MFMA parts, dWo accumulators), all 8 share the items of phases A and B.
+__global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnWBLds l = attnwb_lds(smem);
     dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
@@ -144,12 +145,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_w(AttnBwdArgs a) {
             l.delta[h * DVS_WTOK + i] = delta;
         }
         __syncthreads();
-        // ---- phase B: (key j, head h); at most two items per thread (8 * 48 / 256) --------------------------------
-        f4 dkr[2][2], dvr[2][2];
+        // ---- phase B: (key j, head h); one item per thread (8 * 48 <= 512) -----------------------------------------
+        f4 dkr[1][2], dvr[1][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 1; ++s) {
             dkr[s][0] = dkr[s][1] = dvr[s][0] = dvr[s][1] = f4_zero();
-            const int item = threadIdx.x + 256 * s;
+            const int item = threadIdx.x;
             if (item < 8 * N) {
                 const int j = item >> 3, h = item & 7, c0 = 8 * h;
                 for (int i = 0; i < N; ++i) {
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_w(AttnBwdArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int item = threadIdx.x + 256 * s;
+        for (int s = 0; s < 1; ++s) {
+            const int item = threadIdx.x;
             if (item < 8 * N) {
                 const int j = item >> 3, c0 = 8 * (item & 7);
                 *(f4*)(l.K + j * DVS_LD + c0) = dkr[s][0];
@@ -219,23 +220,23 @@ __global__ __launch_bounds__(256) void k_attn_bwd_w(AttnBwdArgs a) {
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     float* region = (float*)smem;
     dvs_stage_dw<4, 4>(region, aWo, L);
-    float* red = region + DVS_RED_MAT;
+    float* red = region + 2 * DVS_RED_MAT;            // 8 waves x 4096 staged floats precede it
     red[L.wave * 64 + L.lane] = vbo;
     __syncthreads();
     dvs_flush_dw<4, 4>(region, slab + a.o_out_w, L);
     if (threadIdx.x < 64) {
         float s = 0.f;
-        for (int w = 0; w < 4; ++w) s += red[w * 64 + threadIdx.x];
+        for (int w = 0; w < 8; ++w) s += red[w * 64 + threadIdx.x];
         slab[a.o_out_b + threadIdx.x] = s;
     }
 }
 
 void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
     size_t lds = ATTNWB_FLOATS * 4;
-    const size_t red = ((size_t)DVS_RED_MAT + 256) * 4;
+    const size_t red = (2 * (size_t)DVS_RED_MAT + 512) * 4;
     if (lds < red) lds = red;
     DVS_SET_LDS(k_attn_bwd_w, lds);
-    DVS_LAUNCH(k_attn_bwd_w, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_bwd_w, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

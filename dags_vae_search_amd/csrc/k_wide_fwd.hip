@@ -232,7 +232,8 @@ __device__ __forceinline__ AttnWLds attnw_lds(char* smem) {
 }
 constexpr size_t ATTNW_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR;
 
-__global__ __launch_bounds__(256) void k_attn_fwd_w(AttnArgs a) {
+// 8 waves: waves 0..NT-1 own the tiles (MFMA parts), all 8 share the (token, head) items of the core.
+__global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
     DVS_DYN_LDS(smem);
     const AttnWLds l = attnw_lds(smem);
     dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_w(AttnArgs a) {
 void dvs_launch_attn_fwd_w(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ATTNW_FLOATS * 4;
     DVS_SET_LDS(k_attn_fwd_w, lds);
-    DVS_LAUNCH(k_attn_fwd_w, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_attn_fwd_w, dim3(grid), dim3(512), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

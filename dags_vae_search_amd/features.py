@@ -94,6 +94,65 @@ class LabeledDag:
             edges.extend((u, v) for u in range(v) if int(conn[u]) == 1)
         return LabeledGraph(labels, edges)
 
+    def is_valid_graph(self, graph, quiet: bool = True) -> bool:
+        """src/toolkit/labeled.py:186-218: a DAG on num_vertices vertices with labels in range(label_cardinality)."""
+        def fail(msg):
+            if quiet:
+                return False
+            raise AssertionError(msg)
+        if graph is None:
+            return fail("graph is missing")
+        labels, edges = _as_labels_edges(graph)
+        n = len(labels)
+        indeg = [0] * n
+        out = [[] for _ in range(n)]
+        for u, v in edges:
+            if not (0 <= u < n and 0 <= v < n):
+                return fail("graph is not a dag")
+            out[u].append(v)
+            indeg[v] += 1
+        stack = [v for v in range(n) if indeg[v] == 0]
+        seen = 0
+        while stack:
+            u = stack.pop()
+            seen += 1
+            for v in out[u]:
+                indeg[v] -= 1
+                if indeg[v] == 0:
+                    stack.append(v)
+        if seen != n:
+            return fail("graph is not a dag")
+        if n != self.num_vertices:
+            return fail(f"Graph expected to has {self.num_vertices} got instead {n}")
+        for i, label in enumerate(labels):
+            if not (0 <= label < self.label_cardinality):
+                return fail(f"Label of vertex '{i}' expected to be in range 0 ... {self.label_cardinality - 1}, "
+                            f"got instead {label}")
+        return True
+
+    def graph_equals(self, graph1, graph2, attributes_match: bool = True) -> bool:
+        """src/toolkit/labeled.py:238-260: label-preserving isomorphism.  Distinct labels (asia, sachs, card >= n data
+        sets) make the vertex correspondence unique, so this is an edge-set comparison after relabelling; graphs with
+        repeated labels go through networkx's VF2 like the reference (networkx is optional here)."""
+        if graph1 is None or graph2 is None:
+            return False
+        l1, e1 = _as_labels_edges(graph1)
+        l2, e2 = _as_labels_edges(graph2)
+        if len(l1) != len(l2) or len(e1) != len(e2):
+            return False
+        if attributes_match and sorted(l1) != sorted(l2):
+            return False
+        if attributes_match and len(set(l1)) == len(l1):
+            at = {lab: v for v, lab in enumerate(l2)}
+            return sorted((at[l1[u]], at[l1[v]]) for u, v in e1) == sorted(e2)
+        import networkx as nx
+        g1, g2 = nx.DiGraph(), nx.DiGraph()
+        for g, labels, edges in ((g1, l1, e1), (g2, l2, e2)):
+            g.add_nodes_from((v, {LABEL_KEY: lab}) for v, lab in enumerate(labels))
+            g.add_edges_from(edges)
+        match = (lambda a, b: a[LABEL_KEY] == b[LABEL_KEY]) if attributes_match else None
+        return nx.is_isomorphic(g1, g2, node_match=match)
+
     def from_graph_to_dict_writable(self, graph: LabeledGraph) -> Dict:
         es = set(graph.get_edgelist())
         out = {f"{self.dict_label_prefix}{v}": int(graph.labels[v]) for v in range(self.num_vertices)}

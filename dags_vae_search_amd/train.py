@@ -97,3 +97,20 @@ def train_model(model, dataset, epochs: int = 1, batch_size: int = 32, lr: float
             os.makedirs(checkpoint_dir, exist_ok=True)
             torch.save(model.state_dict(), os.path.join(checkpoint_dir, "model_checkpoint_{}.pth".format(epoch)))
     return history
+
+
+def batch_test(toolkit, batch, model, encode_times: int = 10, decode_times: int = 10):
+    """Reconstruction metrics of one batch of labelled graphs (experiments/03_synthetic_12/main.py:200-217):
+    returns (nll, n_valid, n_perfect) over encode_times x decode_times decodes of the posterior means.  Graphs that stop
+    growing early (the reference's decode then raises inside its conversion) count as invalid."""
+    n_valid = 0
+    n_perfect = 0
+    mu, logvar = model.encode(batch)
+    _, nll, _ = model.loss(batch)
+    for _ in range(encode_times):
+        z = mu
+        for _ in range(decode_times):
+            rec = model.decode(z, strict=False)
+            n_valid += sum(toolkit.is_valid_graph(g) for g in rec)
+            n_perfect += sum(toolkit.graph_equals(g0, g1) for g0, g1 in zip(batch, rec))
+    return nll, n_valid, n_perfect

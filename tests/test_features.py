@@ -64,3 +64,32 @@ def test_product_synthetic_generator_matches_oracle_copy():
     a = synthetic_dags(12, 12, 32, seed=9)
     b = ofeat.synthetic_dags(12, 12, 32, seed=9)
     assert [(g.labels, g.edges) for g in a] == [(l, e) for l, e in b]
+
+
+def test_toolkit_validity_and_equality():
+    """LabeledDag.is_valid_graph / graph_equals (src/toolkit/labeled.py:186-260) on the reference's own fixture graph
+    (tests/toolkit/test_labeled.py:49-64) and relabelled / broken variants."""
+    from dags_vae_search_amd import LabeledDag, LabeledGraph
+    tk = LabeledDag(num_vertices=5, label_cardinality=5)
+    g = LabeledGraph([0, 1, 2, 3, 4], [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4)])
+    assert tk.is_valid_graph(g)
+    assert not tk.is_valid_graph(LabeledGraph([0, 1, 2, 3, 9], g.edges))            # label out of range
+    assert not tk.is_valid_graph(LabeledGraph([0, 1, 2, 3], [(0, 1)]))              # wrong size
+    assert not tk.is_valid_graph(LabeledGraph([0, 1, 2, 3, 4], [(0, 1), (1, 0)]))   # cycle
+    assert not tk.is_valid_graph(None)
+    with pytest.raises(AssertionError):
+        tk.is_valid_graph(LabeledGraph([0, 1, 2, 3, 9], g.edges), quiet=False)
+    # same graph with permuted vertex ids
+    perm = [3, 0, 4, 1, 2]
+    h = LabeledGraph([0] * 5, [])
+    for v, lab in enumerate(g.labels):
+        h.labels[perm[v]] = lab
+    h.edges = [(perm[u], perm[v]) for u, v in g.edges]
+    assert tk.graph_equals(g, h)
+    assert not tk.graph_equals(g, LabeledGraph(g.labels, g.edges[:-1] + [(0, 4)]))
+    # repeated labels: isomorphism (needs networkx, as in the reference)
+    pytest.importorskip("networkx")
+    a = LabeledGraph([0, 0, 0], [(0, 1), (1, 2)])
+    b = LabeledGraph([0, 0, 0], [(2, 0), (0, 1)])
+    c = LabeledGraph([0, 0, 0], [(0, 1), (0, 2)])
+    assert tk.graph_equals(a, b) and not tk.graph_equals(a, c)

@@ -67,3 +67,21 @@ def test_decode_reconstructs_asia_test_graphs_at_scale():
     model.seed(4)
     other = model.decode(mu)
     assert any(a.edges != b.edges or a.labels != b.labels for a, b in zip(out, other))
+
+
+def test_batch_test_reconstruction_metrics_asia():
+    """batch_test (experiments/03_synthetic_12/main.py:200-217) on the reference's asia test graphs with its shipped
+    checkpoint: every decoded graph valid, >= 90 % label-preserving-isomorphic to its source (reference at epoch 100:
+    valid 1.000, exact 0.935, 01_bn_asia/main.py:560)."""
+    from dags_vae_search_amd import LabeledDag, LabeledGraph, batch_test
+    from tests.helpers import graphs_from
+    ck = load_npz("asia_ckpt110.npz")
+    cfg = po.PaceConfig(n=8, card=8)
+    model = build_model(cfg, {k: torch.from_numpy(ck[k]) for k in ck.files})
+    graphs = [LabeledGraph(list(l), list(e)) for l, e in graphs_from(load_npz("asia_known_answer.npz"), 8)][:128]
+    toolkit = LabeledDag(num_vertices=8, label_cardinality=8)
+    model.seed(11)
+    nll, n_valid, n_perfect = batch_test(toolkit, graphs, model, encode_times=2, decode_times=3)
+    total = len(graphs) * 6
+    assert n_valid == total and n_perfect >= 0.9 * total
+    assert float(nll) / len(graphs) < 0.5          # reference: recon loss 0.007 per graph at epoch 100

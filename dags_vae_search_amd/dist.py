@@ -37,8 +37,16 @@ def shard_features(features: Dict, rank: int, world: int, num_heads: int = 8) ->
 
 def allreduce_gradients(flat_grads: torch.Tensor, losses: torch.Tensor, group=None):
     """The step's ONE exchange: SUM all-reduce of the flat gradient and of the [total, recon, kld, flag] scalars
-    (RCCL over xGMI on GPUs, gloo in the CPU tests).  Clipping and Adam run AFTER it, replicated on every rank."""
+    (RCCL over xGMI on GPUs, gloo in the CPU tests).  Clipping and Adam run AFTER it, replicated on every rank.
+    ``PaceVaeV3.loss_and_grad`` keeps the four scalars right behind the gradient in one allocation, so both travel in a
+    single collective (the message is ~1.2 MB: latency-bound, a second call would cost as much as the first)."""
     import torch.distributed as dist
-    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
+    if (losses.untyped_storage().data_ptr() == flat_grads.untyped_storage().data_ptr()
+            and losses.storage_offset() == flat_grads.storage_offset() + flat_grads.numel()
+            and flat_grads.is_contiguous() and losses.is_contiguous()):
+        both = torch.as_strided(flat_grads, (flat_grads.numel() + losses.numel(),), (1,), flat_grads.storage_offset())
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
     return flat_grads, losses

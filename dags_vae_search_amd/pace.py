@@ -228,6 +228,8 @@ class PaceVaeV3(nn.Module):
             p.grad = None
         self.flat_params = flat
         self.flat_grads = None
+        self._grad_params = None
+        self._step_losses = None
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -236,12 +238,25 @@ class PaceVaeV3(nn.Module):
         return out
 
     def bind_flat_grads(self) -> torch.Tensor:
-        """Allocate the flat gradient buffer and point every parameter's .grad at its slice."""
+        """Allocate the flat gradient buffer and point every parameter's .grad at its slice (a no-op when they already
+        are: the check looks at the first and last parameter, which is what zero_grad(set_to_none=True) of a stock
+        optimiser would have cleared)."""
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
-            self.flat_grads = torch.zeros_like(self.flat_params)
-        params = dict(self.named_parameters())
-        for (name, off, shp), n in zip(self._table, self._numels):
-            params[name].grad = self.flat_grads[off:off + n].view(shp)
+            # gradient buffer + 4 loss scalars in ONE allocation: the data-parallel step all-reduces both in one call
+            P = self.flat_params.numel()
+            self._grads_and_losses = torch.zeros(P + 4, dtype=torch.float32, device=self.flat_params.device)
+            self.flat_grads = self._grads_and_losses[:P]
+            self._step_losses = self._grads_and_losses[P:]
+            self._grad_params = None
+        if self._grad_params is None:
+            params = dict(self.named_parameters())
+            self._grad_params = [params[name] for name, _, _ in self._table]
+        first, last = self._grad_params[0], self._grad_params[-1]
+        base = self.flat_grads.data_ptr()
+        if (first.grad is None or last.grad is None or first.grad.data_ptr() != base + 4 * self._table[0][1]
+                or last.grad.data_ptr() != base + 4 * self._table[-1][1]):
+            for p, (name, off, shp), n in zip(self._grad_params, self._table, self._numels):
+                p.grad = self.flat_grads[off:off + n].view(shp)
         return self.flat_grads
 
     def _eng(self) -> PaceEngine:
@@ -377,10 +392,10 @@ class PaceVaeV3(nn.Module):
             self._pack(features, check=False if defer_check else None)
         B = eng._ws_batch
         shape = self._shape(B, beta)
-        losses = torch.zeros(4, dtype=torch.float32, device=self.flat_params.device)
+        grads = self.bind_flat_grads()
+        losses = self._step_losses            # tail of the gradient allocation (see bind_flat_grads); rewritten each step
         eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
-        grads = self.bind_flat_grads()
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta

@@ -55,7 +55,7 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
             raise ValueError(f"batch violates the feature invariants (status bits {int(host[4]):#x})")
         if host[3] != 0.0:
             raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
-        return host[0], losses[1], losses[2]
+        return host[0], losses[1].clone(), losses[2].clone()        # `losses` is a reused device buffer
     loss, recon, kld = model.loss_direct(batch)
     loss_value = loss.item()
     loss.backward()

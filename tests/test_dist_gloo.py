@@ -37,9 +37,22 @@ def _worker(rank, world, port, out):
     P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     total, recon, kld = po.loss_direct(P, cfg, shard, training=True, eps=eps_all[lo:hi])
     total.backward()
-    flat = _flat({k: v.grad for k, v in P.items()}, names)
-    losses = torch.tensor([float(total), float(recon), float(kld), 0.0])
-    ddist.allreduce_gradients(flat, losses)
+    g = _flat({k: v.grad for k, v in P.items()}, names)
+    # the product's layout (PaceVaeV3.bind_flat_grads): the 4 loss scalars sit right behind the gradient in ONE
+    # allocation, so allreduce_gradients sends both in a single collective; rank 1 uses separate tensors (two calls) —
+    # both layouts must give the same sums
+    if rank == 0:
+        both = torch.zeros(g.numel() + 4)
+        flat, losses = both[:g.numel()], both[g.numel():]
+        flat.copy_(g)
+        losses.copy_(torch.tensor([float(total), float(recon), float(kld), 0.0]))
+        ddist.allreduce_gradients(flat, losses)
+    else:
+        flat = g.clone()
+        losses = torch.tensor([float(total), float(recon), float(kld), 0.0])
+        both = torch.cat([flat, losses])
+        dist.all_reduce(both)
+        flat, losses = both[:g.numel()].clone(), both[g.numel():].clone()
     # clip AFTER the reduce, then replicated Adam
     coef = min(1.0, 1.0 / (float(flat.norm()) + 1e-6))
     flat_p = _flat(params, names).clone().requires_grad_(True)

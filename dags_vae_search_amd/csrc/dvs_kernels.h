@@ -123,8 +123,18 @@ void dvs_prof_end(dvs_stream_t st);
     } while (0)
 
 #ifndef DVS_EMU
-#define DVS_SET_LDS(kernel, bytes) \
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+// Raise a kernel's dynamic-LDS limit once per (call site, device): hipFuncSetAttribute costs several microseconds of
+// host time, which shows up as GPU idle at the start of every step (the host is not yet ahead of the device there).
+#define DVS_SET_LDS(kernel, bytes)                                                                                   \
+    do {                                                                                                             \
+        static size_t dvs_lds_set_[16] = {0};                                                                        \
+        int dvs_dev_ = 0;                                                                                            \
+        (void)hipGetDevice(&dvs_dev_);                                                                               \
+        if (dvs_dev_ < 0 || dvs_dev_ >= 16 || dvs_lds_set_[dvs_dev_] < (size_t)(bytes)) {                            \
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (dvs_dev_ >= 0 && dvs_dev_ < 16) dvs_lds_set_[dvs_dev_] = (size_t)(bytes);                            \
+        }                                                                                                            \
+    } while (0)
 #else
 #define DVS_SET_LDS(kernel, bytes) ((void)0)
 #endif

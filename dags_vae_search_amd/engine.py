@@ -45,6 +45,7 @@ class PaceEngine:
         self._ws_batch = 0
         self._records: Optional[torch.Tensor] = None
         self._status: Optional[torch.Tensor] = None
+        self._status_external = False
 
     # ---- buffers -------------------------------------------------------------------------------------
     def shape(self, batch, training=False, dropout=0.15, beta=0.005, eps_scale=0.01, dag_offset=0, seed=0):
@@ -59,11 +60,26 @@ class PaceEngine:
             self._ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)   # slab padding must stay 0
             self._ws_batch = batch
             self._records = torch.empty(batch * self.record_bytes, dtype=torch.uint8, device=device)
-            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+            if not self._status_external or self._status.device != device:
+                self._status = torch.zeros(1, dtype=torch.int32, device=device)
+                self._status_external = False
         return self._ws
 
+    def use_status(self, status: torch.Tensor):
+        """Let the caller own the int32[1] feature-validation word (PaceVaeV3 keeps it next to the step's loss scalars so
+        that one small device->host copy per train step reads everything).  It must be zero before a pack/build call
+        with ``zero_status=False``."""
+        self._status = status
+        self._status_external = True
+
+    def _read_status(self) -> int:
+        st = int(self._status.item())
+        if st:
+            self._status.zero_()          # never leave stale bits behind an exception
+        return st
+
     # ---- entry points ----------------------------------------------------------------------------------
-    def pack(self, features: Dict, check: bool = True) -> torch.Tensor:
+    def pack(self, features: Dict, check: bool = True, zero_status: bool = True) -> torch.Tensor:
         """dvs_pack_features: reference-layout dense feature tensors (already on the GPU) -> records."""
         lab = features["vertex_label_features"]
         pos = features["vertex_position_features"]
@@ -77,28 +93,33 @@ class PaceEngine:
             raise AssertionError(f"Expected [B,{self.n_tokens},{self.n_classes}] label features, got {tuple(lab.shape)}")
         if tuple(pos.shape) != (B, N, N) or tuple(adj.shape) != (B, N, N) or tuple(tm.shape) != (8 * B, N, N):
             raise AssertionError("feature tensors have inconsistent shapes")
-        def aligned(t):                     # dvs_pack_features streams with 16-byte loads
-            t = t.contiguous()
+        def aligned(t, dtype):              # dvs_pack_features streams with 16-byte loads
+            if t.dtype != dtype:
+                t = t.to(dtype)
+            if not t.is_contiguous():
+                t = t.contiguous()
             return t if t.data_ptr() % 16 == 0 else t.clone()
-        lab = aligned(lab.float())
-        pos = aligned(pos.float())
-        adj = aligned(adj.float())
-        tm = aligned(tm)
-        tm = tm.view(torch.uint8) if tm.dtype == torch.bool else aligned(tm.to(torch.uint8))
+        lab = aligned(lab, torch.float32)
+        pos = aligned(pos, torch.float32)
+        adj = aligned(adj, torch.float32)
+        tm = aligned(tm, tm.dtype)
+        tm = tm.view(torch.uint8) if tm.dtype == torch.bool else aligned(tm, torch.uint8)
         self.workspace(B, lab.device)
-        self._status.zero_()
+        if zero_status:
+            self._status.zero_()
         shape = self.shape(B)
         dl.check(self.lib, self.lib.dvs_pack_features(ctypes.byref(shape), _ptr(lab), _ptr(pos), _ptr(adj), _ptr(tm),
                                                       _ptr(self._records), _ptr(self._status), _stream()),
                  "dvs_pack_features")
         if check:
-            st = int(self._status.item())
+            st = self._read_status()
             if st:
                 raise ValueError(f"features violate the prepare_features invariants (status bits {st:#x}: "
                                  f"1 = label/position row not one-hot, 2 = per-head masks differ, 4 = self masked)")
         return self._records
 
-    def build_records(self, labels: torch.Tensor, preds: torch.Tensor, check: bool = True) -> torch.Tensor:
+    def build_records(self, labels: torch.Tensor, preds: torch.Tensor, check: bool = True,
+                      zero_status: bool = True) -> torch.Tensor:
         """dvs_build_records: row codec (labels u8 [B,n], preds [B,n]: i16 bit pattern of u16 masks on the one-tile
         path, i64 on the wide path) -> records, all on the device."""
         _require_cuda(labels, "labels")
@@ -109,12 +130,13 @@ class PaceEngine:
         labels = labels.contiguous().to(torch.uint8)
         preds = preds.contiguous().to(torch.int64 if self.wide else torch.int16)
         self.workspace(B, labels.device)
-        self._status.zero_()
+        if zero_status:
+            self._status.zero_()
         shape = self.shape(B)
         dl.check(self.lib, self.lib.dvs_build_records(ctypes.byref(shape), _ptr(labels), _ptr(preds), _ptr(self._records),
                                                       _ptr(self._status), _stream()), "dvs_build_records")
         if check:
-            st = int(self._status.item())
+            st = self._read_status()
             if st:
                 raise ValueError(f"invalid compact DAG batch (status bits {st:#x}: 1 = label out of range, "
                                  f"8 = edge not from a lower to a higher vertex id)")

@@ -243,11 +243,19 @@ class PaceVaeV3(nn.Module):
         optimiser would have cleared)."""
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
             # gradient buffer + 4 loss scalars in ONE allocation: the data-parallel step all-reduces both in one call
+            # ... followed by the int32 feature-validation word, so that ONE small device->host copy ends a train step
             P = self.flat_params.numel()
-            self._grads_and_losses = torch.zeros(P + 4, dtype=torch.float32, device=self.flat_params.device)
+            self._grads_and_losses = torch.zeros(P + 8, dtype=torch.float32, device=self.flat_params.device)
             self.flat_grads = self._grads_and_losses[:P]
-            self._step_losses = self._grads_and_losses[P:]
+            self._step_losses = self._grads_and_losses[P:P + 4]
+            self._step_tail = self._grads_and_losses[P:P + 8]
+            self._step_status = self._grads_and_losses[P + 4:P + 5].view(torch.int32)
+            self._host_tail = torch.zeros(8, dtype=torch.float32)
+            if self.flat_params.is_cuda:
+                self._host_tail = self._host_tail.pin_memory()
             self._grad_params = None
+            if self._engine is not None:
+                self._engine.use_status(self._step_status)
         if self._grad_params is None:
             params = dict(self.named_parameters())
             self._grad_params = [params[name] for name, _, _ in self._table]
@@ -266,6 +274,8 @@ class PaceVaeV3(nn.Module):
         if self._engine is None:
             self._engine = PaceEngine(self._max_num_vertices, self._vertex_label_cardinality)
             assert self._engine.param_floats == self.flat_params.numel()
+            if self.flat_grads is not None and self.flat_grads.device == self.flat_params.device:
+                self._engine.use_status(self._step_status)
         return self._engine
 
     # ---- RNG ------------------------------------------------------------------------------------------------------
@@ -285,17 +295,28 @@ class PaceVaeV3(nn.Module):
                                      self.num_heads, self._graph_label_key, self._graph_label_input,
                                      self._graph_label_output, self._graph_label_start, fixed_memory_len, device)
 
-    def _pack(self, features, check: Optional[bool] = None):
+    def _pack(self, features, check: Optional[bool] = None, zero_status: bool = True):
         eng = self._eng()
         dev = self.flat_params.device
         check = self.nan_check if check is None else check
         if isinstance(features, CompactBatch):       # device-side front-end (records.py): no dense features at all
-            eng.build_records(features.labels.to(dev), features.preds.to(dev), check=check)
+            eng.build_records(features.labels.to(dev), features.preds.to(dev), check=check, zero_status=zero_status)
             return len(features)
         f = {k: features[k].to(dev) for k in ("vertex_label_features", "vertex_position_features",
                                               "adjacency_matrices", "target_masks")}   # pace.py:1981-1984
-        eng.pack(f, check=check)
+        eng.pack(f, check=check, zero_status=zero_status)
         return f["vertex_label_features"].shape[0]
+
+    def read_step(self):
+        """End of a fused train step: ONE pinned device->host copy of [total, recon, kld, non-finite flag, validation
+        bits] and one stream synchronisation; the validation word is re-armed behind the copy, so the next step's first
+        GPU work is its pack kernel.  Returns (losses list of 4 floats, status int)."""
+        self._host_tail.copy_(self._step_tail, non_blocking=True)
+        self._step_status.zero_()
+        torch.cuda.current_stream().synchronize()
+        vals = self._host_tail.tolist()
+        status = int(self._host_tail.view(torch.int32)[4])
+        return vals[:4], status
 
     def _shape(self, batch: int, beta: float):
         return self._eng().shape(batch, training=self.training, dropout=self.dropout, beta=beta, eps_scale=0.01,
@@ -388,11 +409,14 @@ class PaceVaeV3(nn.Module):
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag]; nothing is synchronised."""
         eng = self._eng()
+        if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
+            self.bind_flat_grads()        # first step: allocate (also hands the validation word to the engine)
         if not packed:
-            self._pack(features, check=False if defer_check else None)
+            # defer_check: the validation word is read (and re-armed) by read_step() at the end of the step
+            self._pack(features, check=False if defer_check else None, zero_status=not defer_check)
         B = eng._ws_batch
         shape = self._shape(B, beta)
-        grads = self.bind_flat_grads()
+        grads = self.flat_grads
         losses = self._step_losses            # tail of the gradient allocation (see bind_flat_grads); rewritten each step
         eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
@@ -400,4 +424,5 @@ class PaceVaeV3(nn.Module):
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta
         eng.loss_backward(shape, self.flat_params, self._gcoef, grads)
+        self.bind_flat_grads()            # host-only (re-points .grad views if an optimiser cleared them); GPU is busy
         return losses

@@ -40,7 +40,8 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
     flat gradient, ``group`` (a torch.distributed process group, or True for the default one) SUM-all-reduces it over
     RCCL, and one fused kernel pair clips and applies Adam.  With any other optimiser the reference sequence runs on
     top of the autograd-wrapped kernels (parameters are ordinary leaf tensors with .grad)."""
-    model.train()
+    if not model.training:
+        model.train()
     optimizer.zero_grad()
     if isinstance(optimizer, FusedAdam):
         if optimizer._model is None:
@@ -50,12 +51,13 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
             from .dist import allreduce_gradients
             allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
         optimizer.step(max_grad_norm=max_grad_norm)
-        host = torch.cat([losses, model._engine._status.float()]).tolist()          # the step's only host sync
-        if host[4] != 0.0:
-            raise ValueError(f"batch violates the feature invariants (status bits {int(host[4]):#x})")
+        recon, kld = losses[1].clone(), losses[2].clone()          # `losses` is a reused device buffer
+        host, status = model.read_step()                            # the step's only host sync (one 32-byte copy)
+        if status != 0:
+            raise ValueError(f"batch violates the feature invariants (status bits {status:#x})")
         if host[3] != 0.0:
             raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
-        return host[0], losses[1].clone(), losses[2].clone()        # `losses` is a reused device buffer
+        return host[0], recon, kld
     loss, recon, kld = model.loss_direct(batch)
     loss_value = loss.item()
     loss.backward()

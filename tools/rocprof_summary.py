@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output databases (rocpd sqlite, the default of ROCm 7.x) into the small CSVs kept under
+profiles/.  Usage:
+    tools/rocprof_summary.py stats  <trace_results.db>                  > profiles/rNN_kernel_stats.csv
+    tools/rocprof_summary.py gaps   <trace_results.db>                  (GPU busy / idle per train step)
+    tools/rocprof_summary.py pmc    <db> [<db> ...]                     > profiles/rNN_pmc.csv   (per-dispatch averages)
+    tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   same, from --output-format csv runs
+Counter passes are collected separately (rocprofv3 --kernel-trace --pmc A B ...; gpurun refuses --pmc with --stats)."""
+import collections
+import sqlite3
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def kernels(db):
+    cur = sqlite3.connect(db).cursor()
+    return list(cur.execute("select name, start, end from kernels order by start"))
+
+
+def stats(db):
+    agg = collections.defaultdict(list)
+    for name, s, e in kernels(db):
+        agg[short(name)].append(e - s)
+    total = sum(sum(v) for v in agg.values())
+    print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"')
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print(f'"{k}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{100.0 * sum(v) / total:.2f},{min(v)},{max(v)}')
+
+
+def gaps(db):
+    rows = kernels(db)
+    names = [short(r[0]) for r in rows]
+    idx = [i for i, n in enumerate(names) if n in ("k_pack", "k_pack_w")]
+    print("step,span_us,busy_us,idle_us,largest_gap_us,largest_gap_after")
+    for k, (a, b) in enumerate(zip(idx, idx[1:])):
+        seg = rows[a:b]
+        busy = sum(e - s for _, s, e in seg)
+        span = rows[b][1] - seg[0][1]
+        g = [(seg[i + 1][1] - seg[i][2], names[a + i]) for i in range(len(seg) - 1)] + [(rows[b][1] - seg[-1][2], names[b - 1])]
+        big = max(g)
+        print(f"{k},{span / 1e3:.1f},{busy / 1e3:.1f},{(span - busy) / 1e3:.1f},{big[0] / 1e3:.1f},{big[1]}")
+
+
+def pmc_csv(paths):
+    """rocprofv3 --output-format csv: *_counter_collection.csv files (one row per dispatch and counter)."""
+    import csv
+    table = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    counters = []
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if not k.startswith("k_"):
+                continue
+            table[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = (r["Workgroup_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
+            if r["Counter_Name"] not in counters:
+                counters.append(r["Counter_Name"])
+    print("kernel,dispatches,wg_size,vgpr,agpr,lds_bytes,scratch," + ",".join(counters))
+    for k, d in sorted(table.items(), key=lambda kv: -sum(kv[1].get(counters[0], [0]))):
+        n = max(len(v) for v in d.values())
+        print(k + f",{n}," + ",".join(meta[k]) + "," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))
+
+
+def pmc(dbs):
+    table = collections.defaultdict(lambda: collections.defaultdict(list))
+    counters = []
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        view = "counters_collection" if "counters_collection" in tabs else None
+        if view is None:
+            raise SystemExit(f"{db}: no counters_collection view (tables: {tabs[:12]})")
+        cols = [r[1] for r in cur.execute(f"pragma table_info({view})")]
+        kcol = "kernel_name" if "kernel_name" in cols else "name"
+        for kname, cname, value in cur.execute(f"select {kcol}, counter_name, value from {view}"):
+            table[short(kname)][cname].append(float(value))
+            if cname not in counters:
+                counters.append(cname)
+    print("kernel,dispatches," + ",".join(counters))
+    for k, d in table.items():
+        n = max(len(v) for v in d.values())
+        print(k + f",{n}," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "stats":
+        stats(sys.argv[2])
+    elif mode == "gaps":
+        gaps(sys.argv[2])
+    elif mode == "pmc":
+        pmc(sys.argv[2:])
+    elif mode == "pmc-csv":
+        pmc_csv(sys.argv[2:])
+    else:
+        raise SystemExit(__doc__)

@@ -344,13 +344,17 @@ static inline int site_dec(int layer, int k) { return 16 + 6 * layer + k; }
 // launch grids of the forward kernels
 struct FwdGrids {
     bool wide;
-    int tiles8;     // 8-wave tile-parallel kernels (k_ffn_fwd; one-tile k_attn_fwd / k_embed_fwd / k_loss_fwd)
+    int tiles16;    // 16-wave tile-parallel kernels (k_ffn_fwd, one-tile k_embed_fwd)
+    int attn;       // one-tile k_attn_fwd (DVS_ATTN_FWD_THREADS / 64 waves per workgroup)
+    int tiles8;     // 8-wave tile-parallel kernels (one-tile k_attn_fwd / k_embed_fwd / k_loss_fwd)
     int tiles4;     // 4-wave tile-parallel kernels (k_embed_fwd_w)
     int dags;       // workgroup-per-DAG kernels of the wide path
 };
 static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
     FwdGrids g;
     g.wide = wide;
+    g.tiles16 = grid_for(d.B * d.NT, 16);
+    g.attn = grid_for(d.B * d.NT, dvs_attn_fwd_waves());
     g.tiles8 = grid_for(d.B * d.NT, 8);
     g.tiles4 = grid_for(d.B * d.NT, 4);
     g.dags = grid_for(d.B, 1);
@@ -358,11 +362,11 @@ static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
 }
 static void launch_embed_fwd(const EmbedArgs& e, const FwdGrids& g, dvs_stream_t st) {
     if (g.wide) dvs_launch_embed_fwd_w(e, g.tiles4, st);
-    else dvs_launch_embed_fwd(e, g.tiles8, st);
+    else dvs_launch_embed_fwd(e, g.tiles16, st);
 }
 static void launch_attn_fwd(const AttnArgs& a, const FwdGrids& g, dvs_stream_t st) {
     if (g.wide) dvs_launch_attn_fwd_w(a, g.dags, st);
-    else dvs_launch_attn_fwd(a, g.tiles8, st);
+    else dvs_launch_attn_fwd(a, g.attn, st);
 }
 
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
@@ -417,7 +421,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
             f.ng = P + L.enc[i].n2.w;
             f.nb = P + L.enc[i].n2.b;
         }
-        dvs_launch_ffn_fwd(f, grid.tiles8, st);
+        dvs_launch_ffn_fwd(f, grid.tiles16, st);
         ln = DvsLN{ws + W.stats[sf], P + L.enc[i].n2.w, P + L.enc[i].n2.b};
         prev = sf;
     }
@@ -522,7 +526,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         f.out_stats = ws + W.stats[s2];
         f.site_hidden = site_dec(i, 4);
         f.site_post = site_dec(i, 5);
-        dvs_launch_ffn_fwd(f, grid.tiles8, st);
+        dvs_launch_ffn_fwd(f, grid.tiles16, st);
         ln = DvsLN{ws + W.stats[s2], params + pl.n3.w, params + pl.n3.b};
         prev = s2;
     }

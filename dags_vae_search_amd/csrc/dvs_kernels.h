@@ -105,6 +105,7 @@ void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st);
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st);
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st);
+int dvs_attn_fwd_waves();
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st);
 void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st);

@@ -195,7 +195,7 @@ __device__ __forceinline__ EmbLds emb_lds(char* smem) {
 }
 static size_t emb_lds_floats(int nwaves) { return 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + (size_t)nwaves * 16; }
 
-__global__ __launch_bounds__(512) void k_embed_fwd(EmbedArgs a) {
+__global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
     const EmbLds l = emb_lds(smem);
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(512) void k_embed_fwd(EmbedArgs a) {
 }
 
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = emb_lds_floats(8) * 4;
+    const size_t lds = emb_lds_floats(16) * 4;
     DVS_SET_LDS(k_embed_fwd, lds);
-    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(512), lds, st, a);
+    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(1024), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -369,7 +369,10 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
     return p;
 }
 
-__global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
+#ifndef DVS_ATTN_FWD_THREADS
+#define DVS_ATTN_FWD_THREADS 512
+#endif
+__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
     DVS_DYN_LDS(smem);
     const AttnLds l = attn_lds(smem);
     attn_stage(l, a.in_w, a.in_b, a.out_w, a.out_b, a.ln);
@@ -428,10 +431,11 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
     }
 }
 
+int dvs_attn_fwd_waves() { return DVS_ATTN_FWD_THREADS / 64; }
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attn_lds_floats() * 4;
     DVS_SET_LDS(k_attn_fwd, lds);
-    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(512), lds, st, a);
+    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -454,7 +458,9 @@ __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
 }
 static size_t ffn_lds_floats() { return 128 * DVS_LD + 6 * 64; }
 
-__global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
+// 16 waves per workgroup (112 VGPRs -> 4 waves per SIMD): at B = 4096 every wave owns exactly one DAG and four waves
+// interleave on each SIMD's MFMA pipe.
+__global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
     DVS_DYN_LDS(smem);
     const FfnLds l = ffn_lds(smem);
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(512) void k_ffn_fwd(FfnArgs a) {
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffn_lds_floats() * 4;
     DVS_SET_LDS(k_ffn_fwd, lds);
-    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(512), lds, st, a);
+    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a);
 }
 
 // frag-order [tiles][1024] -> natural [tiles][16][64] (= [B][16*NT][64]) (debug / tests)

@@ -1,18 +1,25 @@
 // Backward kernels: FFN sublayer, stacked-projection (q/k/v) backward with fused LayerNorm backward, slab reduce.
 #include "dvs_backward.h"
+#include "dvs_bf16.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // FFN sublayer backward (autograd of pace.py:62-65 / 151-153).  Recomputes h = drop(relu(W1 x + b1)) from the saved
 // pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
 // ---------------------------------------------------------------------------------------------------------
 struct FfnBLds {
-    float *W1, *W2, *b1, *b2, *lg, *lb, *og, *ob, *slots;
+    // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as fp32 rows: the hidden is recomputed exactly,
+    // because its sign must reproduce the forward's ReLU mask.  The weight GRADIENTS (dvs_coop_dw) stay exact fp32.
+    dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl;
+    float *W1, *b1, *b2, *lg, *lb, *og, *ob, *slots;
 };
 __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     FfnBLds l;
-    l.W1 = (float*)smem;
-    l.W2 = l.W1 + 64 * DVS_LD;
-    l.b1 = l.W2 + 64 * DVS_LD;
+    l.W2Th = (dvs_bf16*)smem;
+    l.W2Tl = l.W2Th + 64 * DVS_LDB;
+    l.W1Th = l.W2Tl + 64 * DVS_LDB;
+    l.W1Tl = l.W1Th + 64 * DVS_LDB;
+    l.W1 = (float*)(l.W1Tl + 64 * DVS_LDB);
+    l.b1 = l.W1 + 64 * DVS_LD;
     l.b2 = l.b1 + 64;
     l.lg = l.b2 + 64;
     l.lb = l.lg + 64;
@@ -21,15 +28,21 @@ __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     l.slots = l.ob + 64;
     return l;
 }
-static size_t ffnb_lds_floats() { return 128 * DVS_LD + 6 * 64 + (size_t)8 * 2 * DVS_SCR + 16; }
+static size_t ffnb_lds_bytes() {
+    return 4 * 64 * DVS_LDB * sizeof(dvs_bf16) + (64 * DVS_LD + 6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
+}
 
 // 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
 // (dvs_coop_dw): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
+// The two gradient products (d hidden, d x) run on the bf16 matrix pipe as bf16x3: gradient
+// parity is bounded at 2e-3 of the tensor maximum (tests), three orders of magnitude above their ~1e-5 error, whereas
+// the forward keeps exact fp32 MFMAs for the 1e-4 ELBO contract.
 __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
     dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
-    dvs_stage_matrix(l.W2, DVS_LD, a.l2_w, 64, 64, 64);
+    dvs_stage_bf_t(l.W2Th, l.W2Tl, a.l2_w, 64, 64);
+    dvs_stage_bf_t(l.W1Th, l.W1Tl, a.l1_w, 64, 64);
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         f4 hpre[4], hd[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) hpre[t] = dvs_vecT(l.b1, t, L);
-        dvs_mat_T<4, 4>(hpre, x, l.W1, DVS_LD, 0, L);
+        dvs_mat_T<4, 4>(hpre, x, l.W1, DVS_LD, 0, L);        // exact fp32: its sign is the ReLU mask of the forward
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         dvs_group_barrier(G, L);
         dvs_coop_dw(aW2, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-        dvs_mat_Tt<4, 4>(dh, dy, l.W2, DVS_LD, 0, L);
+        dvs_matb_T<4>(dh, dvs_split_T(dy), l.W2Th, l.W2Tl, 0, L);
         dvs_dropout_tile(dh, khid, D, L, T.tok0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         f4 dx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] = gp[t];
-        dvs_mat_Tt<4, 4>(dx, dh, l.W1, DVS_LD, 0, L);
+        dvs_matb_T<4>(dx, dvs_split_T(dh), l.W1Th, l.W1Tl, 0, L);
         dvs_group_barrier(G, L);
         if (a.ln.stats) {
             f4 t0[4];
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
 }
 
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = ffnb_lds_floats() * 4;
+    const size_t lds = ffnb_lds_bytes();
     DVS_SET_LDS(k_ffn_bwd, lds);
     DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(512), lds, st, a);
 }
@@ -173,13 +186,17 @@ void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
 template <int NPROJ>
 __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
     DVS_DYN_LDS(smem);
-    float* W = (float*)smem;                       // [64*NPROJ][LD]
-    float* lg = W + 64 * NPROJ * DVS_LD;
+    // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
+    // of the forward depends on it), so it runs on the bf16 matrix pipe; the weight gradients stay exact fp32.
+    dvs_bf16* WTh = (dvs_bf16*)smem;               // [NPROJ][64][LDB]
+    dvs_bf16* WTl = WTh + NPROJ * 64 * DVS_LDB;
+    float* lg = (float*)(WTl + NPROJ * 64 * DVS_LDB);
     float* lb = lg + 64;
     float* slots = lb + 64;                        // per wave 3 tiles: A0, A1 (alternating dY) and B (X)
     int* gcount = (int*)(slots + 8 * 3 * DVS_SCR);
-    if (a.slot_order) dvs_stage_matrix_perm(W, DVS_LD, a.w, 64, 64 * NPROJ, 64, true, false);
-    else dvs_stage_matrix(W, DVS_LD, a.w, 64, 64 * NPROJ, 64);
+#pragma unroll
+    for (int p = 0; p < NPROJ; ++p)
+        dvs_stage_bf_t(WTh + p * 64 * DVS_LDB, WTl + p * 64 * DVS_LDB, a.w + (size_t)p * 4096, 64, 64, a.slot_order != 0);
     if (a.ln.stats) {
         dvs_stage_vector(lg, a.ln.g, 64);
         dvs_stage_vector(lb, a.ln.b, 64);
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
             vb[p] += dvs_colsum(mine, L);
             dvs_group_barrier(G, L);
             dvs_coop_dw(aW[p], slots + (p & 1) * DVS_SCR, slots + 2 * DVS_SCR, 3 * DVS_SCR, L);
-            dvs_mat_Tt<4, 4>(dx, dy, W, DVS_LD, 64 * p, L);
+            dvs_matb_T<4>(dx, dvs_split_T(dy), WTh + p * 64 * DVS_LDB, WTl + p * 64 * DVS_LDB, 0, L);
         }
         dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
         if (a.ln.stats) {
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
 }
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
-    const size_t bytes = ((size_t)64 * nproj * DVS_LD + 128 + (size_t)8 * 3 * DVS_SCR + 16) * 4;
+    const size_t bytes = (size_t)2 * nproj * 64 * DVS_LDB * sizeof(dvs_bf16) + (128 + (size_t)8 * 3 * DVS_SCR + 16) * 4;
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);
         DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(512), bytes, st, a);

@@ -8,16 +8,23 @@
 // q,k (T-layout) feed the score products directly; their N-layout copies (for dq/dk), v^T and dO (N) come from
 // per-wave LDS transposes.
 #include "dvs_backward.h"
+#include "dvs_bf16.h"
 
 struct AttnBLds {
-    float *Win, *Wout, *inb, *outb, *lg, *lb, *slots, *stats;
+    float *inb, *outb, *lg, *lb, *slots, *stats;
+    // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
+    // ~1e-5 perturbation stays a ~1e-5 perturbation of the gradient; the FFN's hidden, whose SIGN is a mask, is recomputed
+    // in exact fp32 instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
+    dvs_bf16 *Winh, *Winl, *WoTh, *WoTl;
     int* gcount;
 };
 __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
     AttnBLds l;
-    l.Win = (float*)smem;
-    l.Wout = l.Win + 192 * DVS_LD;
-    l.inb = l.Wout + 64 * DVS_LD;
+    l.Winh = (dvs_bf16*)smem;
+    l.Winl = l.Winh + 192 * DVS_LDB;
+    l.WoTh = l.Winl + 192 * DVS_LDB;
+    l.WoTl = l.WoTh + 64 * DVS_LDB;
+    l.inb = (float*)(l.WoTl + 64 * DVS_LDB);
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
@@ -26,7 +33,9 @@ __device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
     l.gcount = (int*)(l.stats + 8 * 128);
     return l;
 }
-static size_t attnb_lds_floats() { return 256 * DVS_LD + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16; }
+static size_t attnb_lds_floats() {
+    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
+}
 
 // dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
 // reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
@@ -58,8 +67,8 @@ __device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, cons
 __global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnBLds l = attnb_lds(smem);
-    dvs_stage_matrix_perm(l.Win, DVS_LD, a.in_w, 64, 192, 64, true, false);    // head-aligned slot order (dvs_device.h)
-    dvs_stage_matrix_perm(l.Wout, DVS_LD, a.out_w, 64, 64, 64, false, true);
+    dvs_stage_bf(l.Winh, l.Winl, a.in_w, 64, 192, true, false);                // head-aligned slot order (dvs_device.h)
+    dvs_stage_bf_t(l.WoTh, l.WoTl, a.out_w, 64, 64, false, true);       // image rows = O's slot order
     dvs_stage_vector_perm(l.inb, a.in_b, 192);
     dvs_stage_vector(l.outb, a.out_b, 64);
     if (a.ln.stats) {
@@ -103,9 +112,18 @@ __global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
                 k[t] = dvs_vecT(l.inb + 64, t, L);
                 v[t] = f4_splat(l.inb[128 + 16 * t + L.r]);
             }
-            dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
-            dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
-            dvs_mat_N<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
+            {
+                const SplitT xs = dvs_split_T(x);
+                dvs_matb_T<4>(q, xs, l.Winh, l.Winl, 0, L);
+                if (a.kv) {
+                    const SplitT ks = dvs_split_T(kv);
+                    dvs_matb_T<4>(k, ks, l.Winh, l.Winl, 64, L);
+                    dvs_matb_N<4>(v, ks, l.Winh, l.Winl, 128, L);
+                } else {
+                    dvs_matb_T<4>(k, xs, l.Winh, l.Winl, 64, L);
+                    dvs_matb_N<4>(v, xs, l.Winh, l.Winl, 128, L);
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) q[t] *= scale;
         }
@@ -119,7 +137,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
             vbo += dvs_colsum(sA, L);
 #pragma unroll
             for (int t = 0; t < 4; ++t) dOT[t] = f4_zero();
-            dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
+            dvs_matb_T<4>(dOT, dvs_split_T(dy), l.WoTh, l.WoTl, 0, L);
         }
         dvs_t2n<4>(qN, q, sB, L);
         dvs_t2n<4>(kN, k, sB, L);

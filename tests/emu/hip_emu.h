@@ -54,6 +54,8 @@ constexpr size_t STACK_BYTES = 256 * 1024;
 struct WaveBuf {
     uint32_t a[2][WAVE];
     uint32_t b[2][WAVE];
+    uint32_t a4[2][WAVE][4];      // 8 x bf16 operands of the bf16 MFMA
+    uint32_t b4[2][WAVE][4];
 };
 
 struct Fiber {
@@ -157,6 +159,33 @@ inline dvs_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, dvs_f32x
         float acc = c[reg];
         for (int k = 0; k < 4; ++k)
             acc = fmaf(emu::from_bits<float>(w.a[p][k * 16 + row]), emu::from_bits<float>(w.b[p][k * 16 + col]), acc);
+        d[reg] = acc;
+    }
+    return d;
+}
+
+// ---- MFMA v_mfma_f32_16x16x32_bf16: lane l supplies A[row l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][col l&15];
+//      C/D as above.  bf16 products are exact in fp32; accumulated here as a k-ordered fp32 chain.
+typedef __bf16 dvs_emu_bf8 __attribute__((ext_vector_type(8)));
+inline dvs_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(dvs_emu_bf8 a, dvs_emu_bf8 b, dvs_f32x4 c, int, int, int) {
+    emu::Fiber* f = emu::g_cur;
+    emu::WaveBuf& w = emu::g_block->waves[f->wave];
+    const int p = f->parity;
+    memcpy(w.a4[p][f->lane], &a, 16);
+    memcpy(w.b4[p][f->lane], &b, 16);
+    emu::yield();
+    f->parity ^= 1;
+    const int col = f->lane & 15, g = f->lane >> 4;
+    dvs_f32x4 d = c;
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = 4 * g + reg;
+        float acc = c[reg];
+        for (int kb = 0; kb < 4; ++kb) {
+            dvs_emu_bf8 va, vb;
+            memcpy(&va, w.a4[p][kb * 16 + row], 16);
+            memcpy(&vb, w.b4[p][kb * 16 + col], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)va[e], (float)vb[e], acc);
+        }
         d[reg] = acc;
     }
     return d;

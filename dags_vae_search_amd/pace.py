@@ -369,22 +369,29 @@ class PaceVaeV3(nn.Module):
                           seed=(self._seed << 32) | (self._step & 0xFFFFFFFF))
         raw = eng.decode(shape, self.flat_params, z, uniforms).cpu().numpy()
         self._fwd_generation += 1
-        parents = raw[:, :384].copy().view(np.uint64)            # [B, 48]
-        labels = raw[:, 384:432]
+        labels = raw[:, 384:432].astype(np.int64) - 3
         nv = raw[:, 432:436].copy().view(np.int32)[:, 0]
+        if strict and (nv < N).any():
+            raise IndexError("vertex index out of range")            # igraph's error at pace.py:1296
+        # edges u -> v between user vertices (PACE ids 2 .. N-2), v == 2 skipped (pace.py:1298): unpack the little-endian
+        # 64-bit parent rows into a [B, v, u] bit cube and keep its strict lower triangle
+        cube = np.unpackbits(raw[:, :384].reshape(B, 48, 8), axis=2, bitorder="little")          # [B, 48 (v), 64 (u)]
+        vs = np.arange(3, N - 1)
+        us = np.arange(2, N - 2)
+        bits = cube[:, 3:N - 1, 2:N - 2] & (us[None, None, :] < vs[None, :, None])
+        bb, vi, ui = np.nonzero(bits)
+        starts = np.searchsorted(bb, np.arange(B + 1))
+        ev = (vs[vi] - 2).tolist()
+        eu = (us[ui] - 2).tolist()
+        lab_lists = labels[:, 2:N - 1].tolist()
+        full = (nv >= N).tolist()
         out = []
         for b in range(B):
-            if nv[b] < N:
-                if strict:
-                    raise IndexError("vertex index out of range")    # igraph's error at pace.py:1296
+            if not full[b]:
                 out.append(None)
                 continue
-            lab = [int(labels[b, v]) - 3 for v in range(2, N - 1)]
-            edges = []
-            for v in range(3, N - 1):                                # v == 2 is skipped (pace.py:1298)
-                row = int(parents[b, v])
-                edges.extend((u - 2, v - 2) for u in range(2, v) if (row >> u) & 1)
-            out.append(feat.LabeledGraph(lab, edges))
+            lo, hi = starts[b], starts[b + 1]
+            out.append(feat.LabeledGraph(lab_lists[b], list(zip(eu[lo:hi], ev[lo:hi]))))
         return out
 
     # ---- loss (pace.py:1974-2046) -------------------------------------------------------------------------------

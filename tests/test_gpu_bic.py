@@ -49,3 +49,18 @@ def test_bic_batch_4096_matches_oracle_sample(name, n):
         assert got[b] == pytest.approx(obic.bic(data, card, g.labels, g.edges), abs=1e-7)
     again = ev.score_masks(masks).cpu().numpy()
     assert np.array_equal(got, again)                               # integer counts + fixed-order fp64 sums
+
+
+def test_bic_sort_path_large_parent_sets():
+    """sachs variables with 9 and 10 ternary parents (3^10, 3^11 cells > the LDS table): the sorted-samples counting path
+    against the oracle, plus graphs that mix both paths."""
+    from dags_vae_search_amd import BNLearnWrapper, LabeledGraph
+    data = load_npz("bn_sachs_data.npz")["data"]
+    card = (data.max(0) + 1).astype(np.uint8)
+    ev = BNLearnWrapper("sachs", "bic", data=data)
+    graphs = [LabeledGraph(list(range(11)), [(u, 10) for u in range(10)]),
+              LabeledGraph(list(range(11))[::-1], [(u, 10) for u in range(1, 10)] + [(0, 1)]),
+              LabeledGraph([3, 1, 4, 0, 5, 9, 2, 6, 8, 7, 10], [(u, v) for v in range(11) for u in range(v)])]   # complete DAG
+    got = ev.score_batch(graphs)
+    for g, val in zip(graphs, got):
+        assert val == pytest.approx(obic.bic(data, card, g.labels, g.edges), abs=1e-7)

@@ -125,3 +125,80 @@ __device__ __forceinline__ void dvs_matb_N(f4 (&y)[OT], const SplitT& x, const d
         DVS_SCHED_FENCE();
     }
 }
+
+// ---- bf16x6: three-way split, fp32-accurate -------------------------------------------------------------------------
+// x = hi + mid + lo carries 24 significant bits (each part 8), i.e. the whole fp32 mantissa.  Six MFMAs per product
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped terms are <= 2^-24 of the product) reproduce the fp32 result
+// to ~1e-7 relative at 96 matrix-pipe cycles per K = 32 instead of 256: this is the variant the FORWARD may use, where
+// the 1e-4 ELBO contract leaves no room for bf16x3's 1e-5.
+struct Split3T {
+    bf8 hi[2], mid[2], lo[2];
+};
+__device__ __forceinline__ void dvs_split3_1(float v, dvs_bf16& hi, dvs_bf16& mid, dvs_bf16& lo) {
+    hi = (dvs_bf16)v;
+    const float r1 = v - (float)hi;
+    mid = (dvs_bf16)r1;
+    lo = (dvs_bf16)(r1 - (float)mid);
+}
+__device__ __forceinline__ Split3T dvs_split3_T(const f4 (&x)[4]) {
+    Split3T s;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dvs_bf16 h, m, l;
+            dvs_split3_1(x[2 * p][i], h, m, l);
+            s.hi[p][i] = h;
+            s.mid[p][i] = m;
+            s.lo[p][i] = l;
+            dvs_split3_1(x[2 * p + 1][i], h, m, l);
+            s.hi[p][4 + i] = h;
+            s.mid[p][4 + i] = m;
+            s.lo[p][4 + i] = l;
+        }
+    return s;
+}
+// three images (hi, mid, lo) of rows*DVS_LDB bf16 each, consecutive at img
+__device__ __forceinline__ void dvs_stage_bf3(dvs_bf16* img, const float* __restrict__ src, int ldg, int rows, bool rperm = false,
+                                              bool cperm = false) {
+    dvs_bf16* mid = img + rows * DVS_LDB;
+    dvs_bf16* lo = mid + rows * DVS_LDB;
+    for (int i = threadIdx.x; i < rows * 64; i += blockDim.x) {
+        const int row = i >> 6, col = i & 63;
+        dvs_bf16 h, m, l;
+        dvs_split3_1(src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)], h, m, l);
+        const int o = row * DVS_LDB + dvs_kperm(col);
+        img[o] = h;
+        mid[o] = m;
+        lo[o] = l;
+    }
+}
+// y^T[OT] (T) += W[row0 + 16*OT rows][64] * x^T, W given as the three images of dvs_stage_bf3 (`rows` rows each)
+template <int OT, bool N_LAYOUT = false>
+__device__ __forceinline__ void dvs_matb3(f4 (&y)[OT], const Split3T& x, const dvs_bf16* img, int rows, int row0, const Lane& L) {
+    const dvs_bf16* Wh = img;
+    const dvs_bf16* Wm = img + rows * DVS_LDB;
+    const dvs_bf16* Wl = Wm + rows * DVS_LDB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        bf8 wh[OT], wm[OT], wl[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            wh[ot] = dvs_wfrag(Wh, row0 + 16 * ot + L.r, p, L);
+            wm[ot] = dvs_wfrag(Wm, row0 + 16 * ot + L.r, p, L);
+            wl[ot] = dvs_wfrag(Wl, row0 + 16 * ot + L.r, p, L);
+        }
+        // smallest terms first; N_LAYOUT swaps the operands (result [token][feature] instead of [feature][token])
+#define DVS_M3(wa, xa)                                                                                     \
+    _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)                                                      \
+        y[ot] = N_LAYOUT ? dvs_mfma_bf(xa[p], wa[ot], y[ot]) : dvs_mfma_bf(wa[ot], xa[p], y[ot]);
+        DVS_M3(wl, x.hi)
+        DVS_M3(wh, x.lo)
+        DVS_M3(wm, x.mid)
+        DVS_M3(wm, x.hi)
+        DVS_M3(wh, x.mid)
+        DVS_M3(wh, x.hi)
+#undef DVS_M3
+        DVS_SCHED_FENCE();
+    }
+}

@@ -7,10 +7,11 @@
 // pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
 // ---------------------------------------------------------------------------------------------------------
 struct FfnBLds {
-    // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as fp32 rows: the hidden is recomputed exactly,
-    // because its sign must reproduce the forward's ReLU mask.  The weight GRADIENTS (dvs_coop_dw) stay exact fp32.
-    dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl;
-    float *W1, *b1, *b2, *lg, *lb, *og, *ob, *slots;
+    // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as the bf16x6 triple k_ffn_fwd uses: the hidden is
+    // recomputed with the forward's own instruction sequence, because its sign must reproduce the forward's ReLU mask.
+    // The weight GRADIENTS (dvs_coop_dw) stay exact fp32.
+    dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl, *W1x6;
+    float *b1, *b2, *lg, *lb, *og, *ob, *slots;
 };
 __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     FfnBLds l;
@@ -18,8 +19,8 @@ __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     l.W2Tl = l.W2Th + 64 * DVS_LDB;
     l.W1Th = l.W2Tl + 64 * DVS_LDB;
     l.W1Tl = l.W1Th + 64 * DVS_LDB;
-    l.W1 = (float*)(l.W1Tl + 64 * DVS_LDB);
-    l.b1 = l.W1 + 64 * DVS_LD;
+    l.W1x6 = l.W1Tl + 64 * DVS_LDB;
+    l.b1 = (float*)(l.W1x6 + 3 * 64 * DVS_LDB);
     l.b2 = l.b1 + 64;
     l.lg = l.b2 + 64;
     l.lb = l.lg + 64;
@@ -29,7 +30,7 @@ __device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
     return l;
 }
 static size_t ffnb_lds_bytes() {
-    return 4 * 64 * DVS_LDB * sizeof(dvs_bf16) + (64 * DVS_LD + 6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
+    return 7 * 64 * DVS_LDB * sizeof(dvs_bf16) + (6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
 }
 
 // 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
@@ -40,7 +41,7 @@ static size_t ffnb_lds_bytes() {
 __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
-    dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
+    dvs_stage_bf3(l.W1x6, a.l1_w, 64, 64);
     dvs_stage_bf_t(l.W2Th, l.W2Tl, a.l2_w, 64, 64);
     dvs_stage_bf_t(l.W1Th, l.W1Tl, a.l1_w, 64, 64);
     dvs_stage_vector(l.b1, a.l1_b, 64);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
         f4 hpre[4], hd[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) hpre[t] = dvs_vecT(l.b1, t, L);
-        dvs_mat_T<4, 4>(hpre, x, l.W1, DVS_LD, 0, L);        // exact fp32: its sign is the ReLU mask of the forward
+        dvs_matb3<4>(hpre, dvs_split3_T(x), l.W1x6, 64, 0, L);   // the forward's own bf16x6 product, bit for bit: its sign is the ReLU mask
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -1,6 +1,7 @@
 // Forward kernels of the PACE-VAE step: feature packing, embeddings, attention sublayer, FFN sublayer.
 // One wave owns one DAG (see dvs_device.h); workgroups are persistent and keep the sublayer's weights in LDS.
 #include "dvs_kernels.h"
+#include "dvs_bf16.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // dvs_pack_features: reference-layout dense features -> 96-byte records (replaces pace.py:1981-1985's
@@ -265,24 +266,25 @@ void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
 // -> softmax over keys (in-lane + 2 shuffles) -> O^T = V^T P^T -> y^T = Wo O^T.
 // ---------------------------------------------------------------------------------------------------------
 struct AttnLds {
-    float *Win, *Wout, *inb, *outb, *lg, *lb;
+    dvs_bf16 *Win, *Wout;                     // bf16x6 image triples (dvs_bf16.h); in-projection rows / out-projection columns in slot order
+    float *inb, *outb, *lg, *lb;
 };
 __device__ __forceinline__ AttnLds attn_lds(char* smem) {
     AttnLds l;
-    l.Win = (float*)smem;
-    l.Wout = l.Win + 192 * DVS_LD;
-    l.inb = l.Wout + 64 * DVS_LD;
+    l.Win = (dvs_bf16*)smem;
+    l.Wout = l.Win + 3 * 192 * DVS_LDB;
+    l.inb = (float*)(l.Wout + 3 * 64 * DVS_LDB);
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
     return l;
 }
-static size_t attn_lds_floats() { return 256 * DVS_LD + 192 + 64 + 128; }
+static size_t attn_lds_bytes() { return 3 * 256 * DVS_LDB * sizeof(dvs_bf16) + (192 + 64 + 128) * sizeof(float); }
 
 __device__ __forceinline__ void attn_stage(const AttnLds& l, const float* in_w, const float* in_b, const float* out_w,
                                            const float* out_b, const DvsLN& ln) {
-    dvs_stage_matrix_perm(l.Win, DVS_LD, in_w, 64, 192, 64, true, false);    // rows -> head-aligned slot order
-    dvs_stage_matrix_perm(l.Wout, DVS_LD, out_w, 64, 64, 64, false, true);   // columns likewise
+    dvs_stage_bf3(l.Win, in_w, 64, 192, true, false);      // rows -> head-aligned slot order
+    dvs_stage_bf3(l.Wout, out_w, 64, 64, false, true);     // columns likewise
     dvs_stage_vector_perm(l.inb, in_b, 192);
     dvs_stage_vector(l.outb, out_b, 64);
     if (ln.stats) {
@@ -291,8 +293,8 @@ __device__ __forceinline__ void attn_stage(const AttnLds& l, const float* in_w, 
     }
 }
 
-// q^T, k^T (T-layout, q pre-scaled by 1/sqrt(dh)) and v (N-layout) of one DAG
-__device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], const f4 (&x)[4], const f4 (&kv)[4],
+// q^T, k^T (T-layout, q pre-scaled by 1/sqrt(dh)) and v (N-layout) of one DAG; fp32-accurate bf16x6 products
+__device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], const Split3T& x, const Split3T& kv,
                                          const AttnLds& l, const Lane& L) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -300,9 +302,9 @@ __device__ __forceinline__ void attn_qkv(f4 (&q)[4], f4 (&k)[4], f4 (&v)[4], con
         k[t] = dvs_vecT(l.inb + 64, t, L);
         v[t] = f4_splat(l.inb[128 + 16 * t + L.r]);
     }
-    dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
-    dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
-    dvs_mat_N<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
+    dvs_matb3<4>(q, x, l.Win, 192, 0, L);
+    dvs_matb3<4>(k, kv, l.Win, 192, 64, L);
+    dvs_matb3<4, true>(v, kv, l.Win, 192, 128, L);
     const float scale = 0.35355339059327373f;   // 1/sqrt(8)
 #pragma unroll
     for (int t = 0; t < 4; ++t) q[t] *= scale;
@@ -381,17 +383,20 @@ __global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
     for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
-        f4 x[4], kv[4], dummy[4];
+        f4 x[4], dummy[4];
         float rstd;
         dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
-        if (a.kv) {
-            dvs_load_tile(kv, a.kv, dag, L);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) kv[t] = x[t];
-        }
         f4 q[4], k[4], v[4];
-        attn_qkv(q, k, v, x, kv, l, L);
+        {
+            const Split3T xs = dvs_split3_T(x);
+            if (a.kv) {
+                f4 kv[4];
+                dvs_load_tile(kv, a.kv, dag, L);
+                attn_qkv(q, k, v, xs, dvs_split3_T(kv), l, L);
+            } else {
+                attn_qkv(q, k, v, xs, xs, l, L);
+            }
+        }
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);
-        dvs_mat_T<4, 4>(y, o, l.Wout, DVS_LD, 0, L);
+        dvs_matb3<4>(y, dvs_split3_T(o), l.Wout, 64, 0, L);
         dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
         const bool valid = L.r < N;
 #pragma unroll
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
 
 int dvs_attn_fwd_waves() { return DVS_ATTN_FWD_THREADS / 64; }
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = attn_lds_floats() * 4;
+    const size_t lds = attn_lds_bytes();
     DVS_SET_LDS(k_attn_fwd, lds);
     DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a);
 }
@@ -442,13 +447,14 @@ void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
 // FFN sublayer forward (pace.py:62-65 / 151-153): pre = x + drop(W2 drop(relu(W1 x + b1)) + b2)
 // ---------------------------------------------------------------------------------------------------------
 struct FfnLds {
-    float *W1, *W2, *b1, *b2, *lg, *lb, *ng, *nb;
+    dvs_bf16 *W1, *W2;                        // bf16x6 image triples (dvs_bf16.h): fp32-accurate products on the bf16 pipe
+    float *b1, *b2, *lg, *lb, *ng, *nb;
 };
 __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
     FfnLds l;
-    l.W1 = (float*)smem;
-    l.W2 = l.W1 + 64 * DVS_LD;
-    l.b1 = l.W2 + 64 * DVS_LD;
+    l.W1 = (dvs_bf16*)smem;
+    l.W2 = l.W1 + 3 * 64 * DVS_LDB;
+    l.b1 = (float*)(l.W2 + 3 * 64 * DVS_LDB);
     l.b2 = l.b1 + 64;
     l.lg = l.b2 + 64;
     l.lb = l.lg + 64;
@@ -456,15 +462,14 @@ __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
     l.nb = l.ng + 64;
     return l;
 }
-static size_t ffn_lds_floats() { return 128 * DVS_LD + 6 * 64; }
+static size_t ffn_lds_bytes() { return 6 * 64 * DVS_LDB * sizeof(dvs_bf16) + 6 * 64 * sizeof(float); }
 
-// 16 waves per workgroup (112 VGPRs -> 4 waves per SIMD): at B = 4096 every wave owns exactly one DAG and four waves
-// interleave on each SIMD's MFMA pipe.
+// 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.
 __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
     DVS_DYN_LDS(smem);
     const FfnLds l = ffn_lds(smem);
-    dvs_stage_matrix(l.W1, DVS_LD, a.l1_w, 64, 64, 64);
-    dvs_stage_matrix(l.W2, DVS_LD, a.l2_w, 64, 64, 64);
+    dvs_stage_bf3(l.W1, a.l1_w, 64, 64);
+    dvs_stage_bf3(l.W2, a.l2_w, 64, 64);
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
         f4 h[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] = dvs_vecT(l.b1, t, L);
-        dvs_mat_T<4, 4>(h, x, l.W1, DVS_LD, 0, L);
+        dvs_matb3<4>(h, dvs_split3_T(x), l.W1, 64, 0, L);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.b2, t, L);
-        dvs_mat_T<4, 4>(y, h, l.W2, DVS_LD, 0, L);
+        dvs_matb3<4>(y, dvs_split3_T(h), l.W2, 64, 0, L);
         dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, T.tok0);
         const bool valid = L.r < T.Nl;
 #pragma unroll
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
 }
 
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = ffn_lds_floats() * 4;
+    const size_t lds = ffn_lds_bytes();
     DVS_SET_LDS(k_ffn_fwd, lds);
     DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a);
 }

@@ -93,3 +93,29 @@ def test_toolkit_validity_and_equality():
     b = LabeledGraph([0, 0, 0], [(2, 0), (0, 1)])
     c = LabeledGraph([0, 0, 0], [(0, 1), (0, 2)])
     assert tk.graph_equals(a, b) and not tk.graph_equals(a, c)
+
+
+def test_parquet_datasets_round_trip(tmp_path):
+    """LabeledDagDatasetInMemory / ...Test (experiments/03_synthetic_12/main.py:34-72): parquet rows with the reference's
+    schema -> per-graph feature dicts computed once at load -> pace_collate_fn == prepare_features of the whole batch."""
+    pytest.importorskip("pyarrow")
+    from dags_vae_search_amd import LabeledDag, PaceVaeV3, pace_collate_fn
+    from dags_vae_search_amd.datasets import (LabeledDagDatasetInMemory, LabeledDagDatasetInMemoryTest, read_parquet_rows,
+                                              write_parquet_rows)
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    tk = LabeledDag(num_vertices=8, label_cardinality=8)
+    graphs = synthetic_dags(8, 8, 12, seed=2)
+    path = str(tmp_path / "part.0.parquet")
+    write_parquet_rows(path, tk, graphs)
+    rows = read_parquet_rows(str(tmp_path))
+    assert len(rows) == 12 and rows[0]["e3"] in {"000", "001", "010", "011", "100", "101", "110", "111"}
+    model = PaceVaeV3(8, 8, 32, 8, 3, 64, 32, 32, 0.15)               # CPU: feature preparation needs no GPU
+    ds = LabeledDagDatasetInMemory(str(tmp_path), tk, model)
+    dt = LabeledDagDatasetInMemoryTest(str(tmp_path), tk, model)
+    assert len(ds) == len(dt) == 12
+    assert all(a.labels == b.labels and sorted(a.edges) == sorted(b.edges) for a, b in zip(dt.graphs, graphs))
+    batch = pace_collate_fn([ds[i] for i in range(12)])
+    whole = model.prepare_features(graphs)
+    for k in ("vertex_label_features", "vertex_position_features", "adjacency_matrices", "target_masks"):
+        assert torch.equal(batch[k], whole[k]), k
+    assert batch["num_vertices"] == whole["num_vertices"]

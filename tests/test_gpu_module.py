@@ -366,3 +366,28 @@ def test_batch_8192_per_gpu_shapes(n, B):
     model.seed(4)
     l2 = model.loss_and_grad(f)
     assert torch.equal(l1, l2) and torch.equal(g1, model.flat_grads)
+
+
+def test_train_model_epoch_loop_and_checkpoint_reload(tmp_path):
+    """Row A13: the epoch loop of experiments/03_synthetic_12/main.py:121-198 (shuffled DataLoader over per-graph feature
+    dicts, Adam, ReduceLROnPlateau on the last batch's loss, state_dict per epoch) + load_model_state
+    (src/train_utils.py:11-36) on the saved checkpoint: a reloaded model encodes identically."""
+    from dags_vae_search_amd import LabeledDag, PaceVaeV3, load_model_state, train_model
+    from dags_vae_search_amd.datasets import LabeledDagDatasetInMemory
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    tk = LabeledDag(num_vertices=8, label_cardinality=8)
+    graphs = synthetic_dags(8, 8, 192, seed=6)
+    torch.manual_seed(42)
+    model = PaceVaeV3(8, 8, 32, 8, 3, 64, 32, 32, 0.15).to(DEV)
+    ds = LabeledDagDatasetInMemory(None, tk, model, rows=[tk.from_graph_to_dict_writable(g) for g in graphs])
+    hist = train_model(model, ds, epochs=4, batch_size=32, lr=1e-3, checkpoint_dir=str(tmp_path), log=lambda *_: None)
+    assert len(hist) == 4 and np.isfinite(hist).all() and hist[-1] < hist[0]
+    ck = tmp_path / "model_checkpoint_4.pth"
+    sd = torch.load(ck, weights_only=True)
+    assert len(sd) == 108 and sd["fc3.weight"].shape == (11 * 64, 32)
+    fresh = PaceVaeV3(8, 8, 32, 8, 3, 64, 32, 32, 0.15)
+    load_model_state(fresh, str(ck))
+    fresh = fresh.to(DEV).eval()
+    model.eval()
+    f = model.prepare_features(graphs[:16])
+    assert torch.equal(model.encode_direct(f)[0], fresh.encode_direct(f)[0])

@@ -27,6 +27,14 @@ def main():
     from dags_vae_search_amd import PaceVaeV3
     from oracle import decode as odec
     from oracle import pace_oracle as po
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(min(cores, 16))
     torch.manual_seed(42)
     model = PaceVaeV3(args.n, args.card, 32, 8, 3, 64, 32, 32, 0.15).to("cuda:0").eval()
     z = torch.randn(args.batch, 32, device="cuda:0")

@@ -3,8 +3,8 @@
 profiles/.  Usage:
     tools/rocprof_summary.py stats  <trace_results.db>                  > profiles/rNN_kernel_stats.csv
     tools/rocprof_summary.py gaps   <trace_results.db>                  (GPU busy / idle per train step)
-    tools/rocprof_summary.py pmc    <db> [<db> ...]                     > profiles/rNN_pmc.csv   (per-dispatch averages)
-    tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   same, from --output-format csv runs
+    tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   > profiles/rNN_pmc.csv  (per-dispatch averages;
+                                                                        from rocprofv3 --pmc ... --output-format csv)
 Counter passes are collected separately (rocprofv3 --kernel-trace --pmc A B ...; gpurun refuses --pmc with --stats)."""
 import collections
 import sqlite3
@@ -65,35 +65,12 @@ def pmc_csv(paths):
         print(k + f",{n}," + ",".join(meta[k]) + "," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))
 
 
-def pmc(dbs):
-    table = collections.defaultdict(lambda: collections.defaultdict(list))
-    counters = []
-    for db in dbs:
-        cur = sqlite3.connect(db).cursor()
-        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-        view = "counters_collection" if "counters_collection" in tabs else None
-        if view is None:
-            raise SystemExit(f"{db}: no counters_collection view (tables: {tabs[:12]})")
-        cols = [r[1] for r in cur.execute(f"pragma table_info({view})")]
-        kcol = "kernel_name" if "kernel_name" in cols else "name"
-        for kname, cname, value in cur.execute(f"select {kcol}, counter_name, value from {view}"):
-            table[short(kname)][cname].append(float(value))
-            if cname not in counters:
-                counters.append(cname)
-    print("kernel,dispatches," + ",".join(counters))
-    for k, d in table.items():
-        n = max(len(v) for v in d.values())
-        print(k + f",{n}," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))
-
-
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
         stats(sys.argv[2])
     elif mode == "gaps":
         gaps(sys.argv[2])
-    elif mode == "pmc":
-        pmc(sys.argv[2:])
     elif mode == "pmc-csv":
         pmc_csv(sys.argv[2:])
     else:

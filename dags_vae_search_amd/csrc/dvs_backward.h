@@ -252,17 +252,6 @@ __device__ __forceinline__ void dvs_park_T(float* slot, const f4 (&v)[4], const 
 #pragma unroll
     for (int t = 0; t < 4; ++t) *(f4*)(slot + L.r * DVS_LD + 16 * t + 4 * L.g) = v[t];
 }
-// park an N-layout tile row-major in a slot
-__device__ __forceinline__ void dvs_park_N(float* slot, const f4 (&v)[4], const Lane& L) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float* p = slot + (4 * L.g) * DVS_LD + 16 * t + L.r;
-        p[0] = v[t][0];
-        p[DVS_LD] = v[t][1];
-        p[2 * DVS_LD] = v[t][2];
-        p[3 * DVS_LD] = v[t][3];
-    }
-}
 // sum over the 16 token rows of column `lane` of a parked tile (bias / LayerNorm-parameter gradients: 1 register)
 __device__ __forceinline__ float dvs_colsum(const float* slot, const Lane& L) {
     float s = 0.f;
@@ -312,10 +301,8 @@ __device__ __forceinline__ void dvs_ln_bwd_core(f4 (&dx)[4], const f4 (&xhat)[4]
     for (int t = 0; t < 4; ++t) dx[t] = (dx[t] - s1 - xhat[t] * s2) * rstd;
 }
 
-__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L,
-                                              const float* slot = nullptr) {
-    if (slot) dvs_slot_tile(g, slot, L);
-    else dvs_load_tile(g, base, dag, L);
+__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L) {
+    dvs_load_tile(g, base, dag, L);
     if (L.r >= N) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = f4_zero();

@@ -111,14 +111,6 @@ __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __rest
 // (head 2t + (kk >> 1)), result rows reg <-> head 2t + (reg >> 1).  Scores need 2 unmasked MFMAs per head instead of
 // 4 half-masked ones, and the per-head outputs are merged by register selection.  pi is an involution.
 __device__ __forceinline__ int dvs_pi(int i) { return (i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3); }
-// LDS image dst[row][col] = src[rperm ? pi(row) : row][cperm ? pi(col) : col]
-__device__ __forceinline__ void dvs_stage_matrix_perm(float* dst, int ldl, const float* __restrict__ src, int ldg, int rows,
-                                                      int cols, bool rperm, bool cperm) {
-    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-        const int row = i / cols, col = i - row * cols;
-        dst[row * ldl + col] = src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)];
-    }
-}
 __device__ __forceinline__ void dvs_stage_vector_perm(float* dst, const float* __restrict__ src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[dvs_pi(i)];
 }
@@ -136,7 +128,7 @@ __device__ __forceinline__ f4 dvs_wcol(const float* W, int ld, int col0, int t, 
 __device__ __forceinline__ f4 dvs_vecT(const float* v, int t, const Lane& L) { return *(const f4*)(v + 16 * t + 4 * L.g); }
 
 // ---- register-chained products ----------------------------------------------------------------------------
-// All three walk the contraction in steps of one 16-feature tile: the weight fragments of step s+1 are fetched from
+// Both walk the contraction in steps of one 16-feature tile: the weight fragments of step s+1 are fetched from
 // LDS (double-buffered, 2 x OT float4) while the 4*OT MFMAs of step s issue; a scheduling barrier per step keeps the
 // compiler from hoisting every fragment of the fully unrolled loop to the top (which costs >400 VGPRs and spills).
 // Within a step the contraction index kk is outermost and the output tile innermost, so OT independent accumulator
@@ -158,27 +150,6 @@ __device__ __forceinline__ void dvs_mat_T(f4 (&y)[OT], const f4 (&x)[IT], const 
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(w[ot][kk], x[t][kk], y[ot]);
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) w[ot] = wn[ot];
-        DVS_SCHED_FENCE();
-    }
-}
-// y[OT] (N) += x (T regs used as A) * W^T : y[dt][reg] = Y[token 4g+reg][16dt + r]
-template <int OT, int IT>
-__device__ __forceinline__ void dvs_mat_N(f4 (&y)[OT], const f4 (&x)[IT], const float* W, int ld, int row0, const Lane& L) {
-    f4 w[OT], wn[OT];
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) w[ot] = dvs_wrow(W, ld, row0 + 16 * ot, 0, L);
-#pragma unroll
-    for (int t = 0; t < IT; ++t) {
-        if (t + 1 < IT) {
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) wn[ot] = dvs_wrow(W, ld, row0 + 16 * ot, t + 1, L);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) y[ot] = dvs_mfma(x[t][kk], w[ot][kk], y[ot]);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) w[ot] = wn[ot];
         DVS_SCHED_FENCE();
@@ -259,45 +230,6 @@ __device__ __forceinline__ void dvs_store_tile(float* __restrict__ base, size_t 
     f4* p = (f4*)(base + dag * DVS_TILE) + L.lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) p[t * 64] = x[t];
-}
-
-// ---- LDS-DMA prefetch of the next DAG's tiles --------------------------------------------------------------------
-// Backward kernels run one wave per SIMD (their weight-gradient accumulators fill the register file), so nothing
-// hides the HBM latency of a DAG's input tiles.  Each wave therefore keeps a private LDS landing zone and, as soon as
-// it has copied the current DAG's tiles into registers, streams the NEXT DAG's tiles into it with
-// global_load_lds_dwordx4 (no registers, no wait): a frag-order tile is exactly the lane-linear 4 x 1 KiB image the
-// LDS-DMA writes.  At the top of the next iteration one s_waitcnt vmcnt(0) + 4 ds_read_b128 per tile replace the
-// exposed round trip to HBM.
-#ifdef DVS_EMU
-#define DVS_GLDS16(gptr, lptr, lane) memcpy((char*)(lptr) + (lane) * 16, (const void*)(gptr), 16)
-#define DVS_WAIT_VM() ((void)0)
-#define DVS_WAIT_LGKM() ((void)0)
-#else
-#define DVS_GLDS16(gptr, lptr, lane)                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-#define DVS_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define DVS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-// request tile `dag` of a frag-order buffer into this wave's LDS slot (4 x 1 KiB, lane-linear)
-__device__ __forceinline__ void dvs_prefetch_tile(float* slot, const float* __restrict__ base, size_t dag, const Lane& L) {
-    const float* g = base + dag * DVS_TILE + L.lane * 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) DVS_GLDS16(g + t * 256, slot + t * 256, L.lane);
-}
-// all requested tiles have landed (call once per iteration, before dvs_slot_tile)
-__device__ __forceinline__ void dvs_prefetch_wait() {
-    DVS_WAIT_VM();
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void dvs_slot_tile(f4 (&x)[4], const float* slot, const Lane& L) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = *(const f4*)(slot + t * 256 + L.lane * 4);
-}
-// the slot's contents are in registers: the slot may be overwritten by the next request
-__device__ __forceinline__ void dvs_slot_release() {
-    DVS_WAIT_LGKM();
-    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- reductions over the 64 features of a token (T-layout: 16 in-lane values x 4 lane groups g) --------------

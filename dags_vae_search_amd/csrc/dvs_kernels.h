@@ -174,13 +174,11 @@ __device__ __forceinline__ DvsDrop dvs_drop_of(const DvsDims& d) {
 // Rows of padding tokens (r >= N) are forced to zero.  xhat (optional) receives the normalised value.
 template <bool WANT_XHAT>
 __device__ __forceinline__ void dvs_load_x(f4 (&x)[4], f4 (&xhat)[4], float& rstd, const float* xin, const DvsLN& ln,
-                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L,
-                                           const float* slot = nullptr) {
+                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L) {
     // whole-vector arithmetic only (element-wise updates of the loaded vectors inside the branch made hipcc route
-    // them through scratch memory).  slot != null: the tile was prefetched into this wave's LDS slot.
+    // them through scratch memory)
     f4 raw[4];
-    if (slot) dvs_slot_tile(raw, slot, L);
-    else dvs_load_tile(raw, xin, dag, L);
+    dvs_load_tile(raw, xin, dag, L);
     const float vm = L.r < N ? 1.f : 0.f;
     float mean = 0.f, rs = 1.f;
     const bool has_ln = ln.stats != nullptr;

@@ -15,7 +15,8 @@
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWBLds {
     float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
-    uint64_t* al;
+    uint64_t* al;                // [48] ancestor bit-rows: whom token i attends
+    uint64_t* de;                // [48] descendant bit-rows: who attends token j
 };
 __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     AttnWBLds l;
@@ -34,9 +35,10 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     l.lse = l.DQ + DVS_WSCR;                     // [8][48]
     l.delta = l.lse + 8 * DVS_WTOK;              // [8][48]
     l.al = (uint64_t*)(l.delta + 8 * DVS_WTOK);  // [48] (offset is a multiple of 8 bytes)
+    l.de = l.al + DVS_WTOK;
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 2 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 4 * DVS_WTOK;
 
 // 8 waves: waves 0..NT-1 own the tiles (MFMA parts, dWo accumulators), all 8 share the items of phases A and B.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
@@ -103,45 +105,58 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             dvs_park_T(l.DO + tok0 * DVS_LD, dOT, L);
         }
         __syncthreads();
+        if (threadIdx.x < DVS_WTOK) {                     // descendant rows for phase B (l.al was written before the barrier)
+            const int j = threadIdx.x;
+            uint64_t d = 0;
+            for (int i = 0; i < N; ++i) d |= ((l.al[i] >> j) & 1ull) << i;
+            l.de[j] = d;
+        }
         // ---- phase A: (query i, head h) ---------------------------------------------------------------------------
+        // ONE pass over the ancestor row, two keys per iteration (the walk is latency-bound): with e_j = exp(s_j - m) for a
+        // running maximum m, the sums den = S e, O' = S e mk v, D' = S e dp, A' = S e dp k, B' = S e k are rescaled whenever m
+        // grows; then p = e / den gives  O = O'/den,  delta = D'/den,  dq = S p (dp - delta) k = (A' - delta B') / den.
         for (int item = threadIdx.x; item < 8 * N; item += blockDim.x) {
             const int i = item >> 3, h = item & 7, c0 = 8 * h;
             const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + c0), q1 = *(const f4*)(l.Q + i * DVS_LD + c0 + 4);
             const f4 g0 = *(const f4*)(l.DO + i * DVS_LD + c0), g1 = *(const f4*)(l.DO + i * DVS_LD + c0 + 4);
-            const uint64_t al = l.al[i];
-            float mx = -3.0e38f;
-            for (uint64_t m = al; m; m &= m - 1) mx = fmaxf(mx, dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + c0));
-            float den = 0.f;
-            for (uint64_t m = al; m; m &= m - 1) den += __expf(dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + c0) - mx);
-            const float lse = mx + __logf(den);
-            float delta = 0.f;
-            f4 o0 = f4_zero(), o1 = f4_zero();
-            for (uint64_t m = al; m; m &= m - 1) {
-                const int j = dvs_ctz64(m);
-                const float p = __expf(dvs_dot8(q0, q1, l.K + j * DVS_LD + c0) - lse);
-                const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
-                const float* vp = l.V + j * DVS_LD + c0;
-                const float dp = mk * dvs_dot8(g0, g1, vp);
-                delta += p * dp;
-                const float pm = p * mk;
-                o0 += *(const f4*)vp * pm;
-                o1 += *(const f4*)(vp + 4) * pm;
+            float m = -3.0e38f, den = 0.f, dsum = 0.f;
+            f4 o0 = f4_zero(), o1 = f4_zero(), a0 = f4_zero(), a1 = f4_zero(), b0 = f4_zero(), b1 = f4_zero();
+            for (uint64_t mm = l.al[i]; mm;) {
+                const int j0 = dvs_ctz64(mm);
+                mm &= mm - 1;
+                const bool two = mm != 0;
+                const int j1 = two ? dvs_ctz64(mm) : j0;
+                mm &= mm - 1;
+                const float* k0p = l.K + j0 * DVS_LD + c0;
+                const float* k1p = l.K + j1 * DVS_LD + c0;
+                const float* v0p = l.V + j0 * DVS_LD + c0;
+                const float* v1p = l.V + j1 * DVS_LD + c0;
+                const float s0 = dvs_dot8(q0, q1, k0p);
+                const float s1 = two ? dvs_dot8(q0, q1, k1p) : -3.0e38f;
+                const float mn = fmaxf(m, fmaxf(s0, s1));
+                const float sc = __expf(m - mn);
+                const float e0 = __expf(s0 - mn), e1 = two ? __expf(s1 - mn) : 0.f;
+                const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j0), D) : 1.0f;
+                const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j1), D) : 1.0f;
+                const float dp0 = mk0 * dvs_dot8(g0, g1, v0p), dp1 = mk1 * dvs_dot8(g0, g1, v1p);
+                den = den * sc + (e0 + e1);
+                dsum = dsum * sc + (e0 * dp0 + e1 * dp1);
+                const float w0 = e0 * mk0, w1 = e1 * mk1, x0 = e0 * dp0, x1 = e1 * dp1;
+                o0 = o0 * sc + *(const f4*)v0p * w0 + *(const f4*)v1p * w1;
+                o1 = o1 * sc + *(const f4*)(v0p + 4) * w0 + *(const f4*)(v1p + 4) * w1;
+                a0 = a0 * sc + *(const f4*)k0p * x0 + *(const f4*)k1p * x1;
+                a1 = a1 * sc + *(const f4*)(k0p + 4) * x0 + *(const f4*)(k1p + 4) * x1;
+                b0 = b0 * sc + *(const f4*)k0p * e0 + *(const f4*)k1p * e1;
+                b1 = b1 * sc + *(const f4*)(k0p + 4) * e0 + *(const f4*)(k1p + 4) * e1;
+                m = mn;
             }
-            f4 dq0 = f4_zero(), dq1 = f4_zero();
-            for (uint64_t m = al; m; m &= m - 1) {
-                const int j = dvs_ctz64(m);
-                const float* kp = l.K + j * DVS_LD + c0;
-                const float p = __expf(dvs_dot8(q0, q1, kp) - lse);
-                const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
-                const float ds = p * (mk * dvs_dot8(g0, g1, l.V + j * DVS_LD + c0) - delta);
-                dq0 += *(const f4*)kp * ds;
-                dq1 += *(const f4*)(kp + 4) * ds;
-            }
-            *(f4*)(l.O + i * DVS_LD + c0) = o0;
-            *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1;
-            *(f4*)(l.DQ + i * DVS_LD + c0) = dq0 * scale;
-            *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = dq1 * scale;
-            l.lse[h * DVS_WTOK + i] = lse;
+            const float rden = 1.0f / den;
+            const float delta = dsum * rden;
+            *(f4*)(l.O + i * DVS_LD + c0) = o0 * rden;
+            *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1 * rden;
+            *(f4*)(l.DQ + i * DVS_LD + c0) = (a0 - b0 * delta) * (rden * scale);
+            *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = (a1 - b1 * delta) * (rden * scale);
+            l.lse[h * DVS_WTOK + i] = m + __logf(den);
             l.delta[h * DVS_WTOK + i] = delta;
         }
         __syncthreads();
@@ -153,21 +168,32 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             const int item = threadIdx.x;
             if (item < 8 * N) {
                 const int j = item >> 3, h = item & 7, c0 = 8 * h;
-                for (int i = 0; i < N; ++i) {
-                    if (!((l.al[i] >> j) & 1ull)) continue;
-                    const float* qp = l.Q + i * DVS_LD + c0;
-                    const float* gp = l.DO + i * DVS_LD + c0;
+                const float* kp = l.K + j * DVS_LD + c0;
+                const float* vp = l.V + j * DVS_LD + c0;
+                for (uint64_t mm = l.de[j]; mm;) {                 // the queries that attend j, two per iteration
+                    const int i0 = dvs_ctz64(mm);
+                    mm &= mm - 1;
+                    const bool two = mm != 0;
+                    const int i1 = two ? dvs_ctz64(mm) : i0;
+                    mm &= mm - 1;
+                    const float* q0p = l.Q + i0 * DVS_LD + c0;
+                    const float* q1p = l.Q + i1 * DVS_LD + c0;
+                    const float* g0p = l.DO + i0 * DVS_LD + c0;
+                    const float* g1p = l.DO + i1 * DVS_LD + c0;
                     // same operand order as phase A (q . k, dO . v): bitwise the same scores
-                    const f4 qa = *(const f4*)qp, qb = *(const f4*)(qp + 4);
-                    const f4 ga = *(const f4*)gp, gb = *(const f4*)(gp + 4);
-                    const float p = __expf(dvs_dot8(qa, qb, l.K + j * DVS_LD + c0) - l.lse[h * DVS_WTOK + i]);
-                    const float mk = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D) : 1.0f;
-                    const float ds = p * (mk * dvs_dot8(ga, gb, l.V + j * DVS_LD + c0) - l.delta[h * DVS_WTOK + i]);
-                    const float pm = p * mk;
-                    dkr[s][0] += qa * ds;
-                    dkr[s][1] += qb * ds;
-                    dvr[s][0] += ga * pm;
-                    dvr[s][1] += gb * pm;
+                    const f4 qa0 = *(const f4*)q0p, qb0 = *(const f4*)(q0p + 4), qa1 = *(const f4*)q1p, qb1 = *(const f4*)(q1p + 4);
+                    const f4 ga0 = *(const f4*)g0p, gb0 = *(const f4*)(g0p + 4), ga1 = *(const f4*)g1p, gb1 = *(const f4*)(g1p + 4);
+                    const float p0 = __expf(dvs_dot8(qa0, qb0, kp) - l.lse[h * DVS_WTOK + i0]);
+                    const float p1 = two ? __expf(dvs_dot8(qa1, qb1, kp) - l.lse[h * DVS_WTOK + i1]) : 0.f;
+                    const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i0) * NTOK + j), D) : 1.0f;
+                    const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i1) * NTOK + j), D) : 1.0f;
+                    const float ds0 = p0 * (mk0 * dvs_dot8(ga0, gb0, vp) - l.delta[h * DVS_WTOK + i0]);
+                    const float ds1 = p1 * (mk1 * dvs_dot8(ga1, gb1, vp) - l.delta[h * DVS_WTOK + i1]);
+                    const float pm0 = p0 * mk0, pm1 = p1 * mk1;
+                    dkr[s][0] += qa0 * ds0 + qa1 * ds1;
+                    dkr[s][1] += qb0 * ds0 + qb1 * ds1;
+                    dvr[s][0] += ga0 * pm0 + ga1 * pm1;
+                    dvr[s][1] += gb0 * pm0 + gb1 * pm1;
                 }
             }
         }

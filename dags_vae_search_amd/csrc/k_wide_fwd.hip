@@ -289,20 +289,36 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
             const int i = item >> 3, h = item & 7;
             const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + 8 * h), q1 = *(const f4*)(l.Q + i * DVS_LD + 8 * h + 4);
             const uint64_t al = rec->allowed[i];
-            float mx = -3.0e38f;
-            for (uint64_t m = al; m; m &= m - 1) mx = fmaxf(mx, dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + 8 * h));
-            float den = 0.f;
-            for (uint64_t m = al; m; m &= m - 1) den += __expf(dvs_dot8(q0, q1, l.K + dvs_ctz64(m) * DVS_LD + 8 * h) - mx);
-            const float rden = 1.0f / den;
+            // ONE pass over the ancestor row with an online softmax (running max m, denominator and output rescaled
+            // when m grows), two keys per iteration so that their LDS reads overlap: the row walk is latency-bound.
+            // Dropout acts on the normalised probabilities; it commutes with the final division by the denominator.
+            float m = -3.0e38f, den = 0.f;
             f4 o0 = f4_zero(), o1 = f4_zero();
-            for (uint64_t m = al; m; m &= m - 1) {
-                const int j = dvs_ctz64(m);
-                float p = __expf(dvs_dot8(q0, q1, l.K + j * DVS_LD + 8 * h) - mx) * rden;
-                if (D.on) p = dvs_dropout_elem(p, kprob, (uint32_t)((h * NTOK + i) * NTOK + j), D);
-                const float* vp = l.V + j * DVS_LD + 8 * h;
-                o0 += *(const f4*)vp * p;
-                o1 += *(const f4*)(vp + 4) * p;
+            for (uint64_t mm = al; mm;) {
+                const int j0 = dvs_ctz64(mm);
+                mm &= mm - 1;
+                const bool two = mm != 0;
+                const int j1 = two ? dvs_ctz64(mm) : j0;
+                mm &= mm - 1;                                   // no-op on 0
+                const float s0 = dvs_dot8(q0, q1, l.K + j0 * DVS_LD + 8 * h);
+                const float s1 = two ? dvs_dot8(q0, q1, l.K + j1 * DVS_LD + 8 * h) : -3.0e38f;
+                const float mn = fmaxf(m, fmaxf(s0, s1));
+                const float sc = __expf(m - mn);
+                float e0 = __expf(s0 - mn), e1 = two ? __expf(s1 - mn) : 0.f;
+                den = den * sc + (e0 + e1);
+                if (D.on) {
+                    e0 = dvs_dropout_elem(e0, kprob, (uint32_t)((h * NTOK + i) * NTOK + j0), D);
+                    e1 = dvs_dropout_elem(e1, kprob, (uint32_t)((h * NTOK + i) * NTOK + j1), D);
+                }
+                const float* v0 = l.V + j0 * DVS_LD + 8 * h;
+                const float* v1 = l.V + j1 * DVS_LD + 8 * h;
+                o0 = o0 * sc + *(const f4*)v0 * e0 + *(const f4*)v1 * e1;
+                o1 = o1 * sc + *(const f4*)(v0 + 4) * e0 + *(const f4*)(v1 + 4) * e1;
+                m = mn;
             }
+            const float rden = 1.0f / den;
+            o0 *= rden;
+            o1 *= rden;
             *(f4*)(l.O + i * DVS_LD + 8 * h) = o0;
             *(f4*)(l.O + i * DVS_LD + 8 * h + 4) = o1;
         }

@@ -57,6 +57,55 @@ __device__ __forceinline__ float dvs_dot8(const f4& a0, const f4& a1, const floa
     return s;
 }
 
+// ---- attention-core item layout ------------------------------------------------------------------------------------------
+// One lane walks the bit-row of one (token, head); a wave runs for its longest row and the rows of late tokens are the
+// long ones (up to N keys).  The core phases have 512 lanes for 8N <= 384 items, so the LAST nsplit = min(N, 64 - N)
+// tokens get a lane PAIR per (token, head): each lane of the pair walks every other set bit of the row (rowE / rowO,
+// prepared once per DAG), and the two partial online-softmax states are merged with one DPP exchange (lane ^ 1).
+struct DvsCoreItem {
+    int tok, head, half;         // half: -1 = whole row, 0 / 1 = even / odd set bits; tok < 0: idle lane
+};
+__device__ __forceinline__ DvsCoreItem dvs_core_item(int N) {
+    int nsplit = 64 - N;
+    nsplit = nsplit < 0 ? 0 : (nsplit > N ? N : nsplit);
+    const int single = 8 * (N - nsplit), t = threadIdx.x;
+    DvsCoreItem it;
+    if (t < single) {
+        it.tok = t >> 3;
+        it.head = t & 7;
+        it.half = -1;
+    } else {
+        const int u = t - single;
+        it.tok = (N - nsplit) + (u >> 4);
+        it.head = (u >> 1) & 7;
+        it.half = u & 1;
+        if (it.tok >= N) it.tok = -1;
+    }
+    return it;
+}
+// split a bit-row into its even- and odd-ordinal set bits
+__device__ __forceinline__ void dvs_split_row(uint64_t row, uint64_t& even, uint64_t& odd) {
+    even = 0;
+    odd = 0;
+    bool e = true;
+    for (uint64_t m = row; m; m &= m - 1) {
+        const uint64_t bit = m & (~m + 1);
+        if (e) even |= bit; else odd |= bit;
+        e = !e;
+    }
+}
+// value held by lane (lane ^ 1)
+__device__ __forceinline__ float dvs_pair_xchg(float v) {
+#ifdef DVS_EMU
+    return emu::exchange(v, emu::g_cur->lane ^ 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+#endif
+}
+__device__ __forceinline__ f4 dvs_pair_xchg(const f4& v) {
+    return f4{dvs_pair_xchg(v[0]), dvs_pair_xchg(v[1]), dvs_pair_xchg(v[2]), dvs_pair_xchg(v[3])};
+}
+
 // ---- LDS images shared by the forward and backward kernels ---------------------------------------------------------
 constexpr int EMBW_LABLD = DVS_WTOK;             // labw image [32][48]
 struct EmbWLds {

@@ -15,8 +15,8 @@
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWBLds {
     float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
-    uint64_t* al;                // [48] ancestor bit-rows: whom token i attends
-    uint64_t* de;                // [48] descendant bit-rows: who attends token j
+    uint64_t* al;                // [3][48] ancestor bit-rows (whom token i attends), their even / odd set bits
+    uint64_t* de;                // [3][48] descendant bit-rows (who attends token j), likewise
 };
 __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     AttnWBLds l;
@@ -35,10 +35,10 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     l.lse = l.DQ + DVS_WSCR;                     // [8][48]
     l.delta = l.lse + 8 * DVS_WTOK;              // [8][48]
     l.al = (uint64_t*)(l.delta + 8 * DVS_WTOK);  // [48] (offset is a multiple of 8 bytes)
-    l.de = l.al + DVS_WTOK;
+    l.de = l.al + 3 * DVS_WTOK;
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 4 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 12 * DVS_WTOK;
 
 // 8 waves: waves 0..NT-1 own the tiles (MFMA parts, dWo accumulators), all 8 share the items of phases A and B.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
@@ -71,7 +71,15 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
         const size_t tile = (size_t)dag * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        if (threadIdx.x < DVS_WTOK) l.al[threadIdx.x] = (int)threadIdx.x < N ? rec->allowed[threadIdx.x] : 0ull;
+        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {      // a wave without a tile prepares the rows
+            const int i = threadIdx.x - 256;
+            const uint64_t row = i < N ? rec->allowed[i] : 0ull;
+            uint64_t e, o;
+            dvs_split_row(row, e, o);
+            l.al[i] = row;
+            l.al[DVS_WTOK + i] = e;
+            l.al[2 * DVS_WTOK + i] = o;
+        }
         f4 dy[4];
         if (has_tile) {
             f4 x[4], kv[4], dummy[4];
@@ -105,23 +113,29 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             dvs_park_T(l.DO + tok0 * DVS_LD, dOT, L);
         }
         __syncthreads();
-        if (threadIdx.x < DVS_WTOK) {                     // descendant rows for phase B (l.al was written before the barrier)
-            const int j = threadIdx.x;
+        const DvsCoreItem it = dvs_core_item(N);          // (token, head[, half]) of this lane in phases A and B
+        const bool active = it.tok >= 0;
+        if (threadIdx.x >= 448 && threadIdx.x < 448 + DVS_WTOK) {       // descendant rows for phase B (rows are complete: barrier above)
+            const int j = threadIdx.x - 448;
             uint64_t d = 0;
             for (int i = 0; i < N; ++i) d |= ((l.al[i] >> j) & 1ull) << i;
+            uint64_t e, o;
+            dvs_split_row(d, e, o);
             l.de[j] = d;
+            l.de[DVS_WTOK + j] = e;
+            l.de[2 * DVS_WTOK + j] = o;
         }
         // ---- phase A: (query i, head h) ---------------------------------------------------------------------------
-        // ONE pass over the ancestor row, two keys per iteration (the walk is latency-bound): with e_j = exp(s_j - m) for a
-        // running maximum m, the sums den = S e, O' = S e mk v, D' = S e dp, A' = S e dp k, B' = S e k are rescaled whenever m
-        // grows; then p = e / den gives  O = O'/den,  delta = D'/den,  dq = S p (dp - delta) k = (A' - delta B') / den.
-        for (int item = threadIdx.x; item < 8 * N; item += blockDim.x) {
-            const int i = item >> 3, h = item & 7, c0 = 8 * h;
+        // ONE pass over the (half) ancestor row, two keys per iteration (the walk is latency-bound): with e_j = exp(s_j - m)
+        // for a running maximum m, the sums den = S e, O' = S e mk v, D' = S e dp, A' = S e dp k, B' = S e k are rescaled
+        // whenever m grows; then p = e / den gives O = O'/den, delta = D'/den, dq = S p (dp - delta) k = (A' - delta B')/den.
+        {
+            const int i = active ? it.tok : 0, h = it.head, c0 = 8 * h;
             const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + c0), q1 = *(const f4*)(l.Q + i * DVS_LD + c0 + 4);
             const f4 g0 = *(const f4*)(l.DO + i * DVS_LD + c0), g1 = *(const f4*)(l.DO + i * DVS_LD + c0 + 4);
             float m = -3.0e38f, den = 0.f, dsum = 0.f;
             f4 o0 = f4_zero(), o1 = f4_zero(), a0 = f4_zero(), a1 = f4_zero(), b0 = f4_zero(), b1 = f4_zero();
-            for (uint64_t mm = l.al[i]; mm;) {
+            for (uint64_t mm = active ? l.al[(it.half + 1) * DVS_WTOK + i] : 0ull; mm;) {
                 const int j0 = dvs_ctz64(mm);
                 mm &= mm - 1;
                 const bool two = mm != 0;
@@ -150,64 +164,84 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
                 b1 = b1 * sc + *(const f4*)(k0p + 4) * e0 + *(const f4*)(k1p + 4) * e1;
                 m = mn;
             }
-            const float rden = 1.0f / den;
-            const float delta = dsum * rden;
-            *(f4*)(l.O + i * DVS_LD + c0) = o0 * rden;
-            *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1 * rden;
-            *(f4*)(l.DQ + i * DVS_LD + c0) = (a0 - b0 * delta) * (rden * scale);
-            *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = (a1 - b1 * delta) * (rden * scale);
-            l.lse[h * DVS_WTOK + i] = m + __logf(den);
-            l.delta[h * DVS_WTOK + i] = delta;
-        }
-        __syncthreads();
-        // ---- phase B: (key j, head h); one item per thread (8 * 48 <= 512) -----------------------------------------
-        f4 dkr[1][2], dvr[1][2];
-#pragma unroll
-        for (int s = 0; s < 1; ++s) {
-            dkr[s][0] = dkr[s][1] = dvr[s][0] = dvr[s][1] = f4_zero();
-            const int item = threadIdx.x;
-            if (item < 8 * N) {
-                const int j = item >> 3, h = item & 7, c0 = 8 * h;
-                const float* kp = l.K + j * DVS_LD + c0;
-                const float* vp = l.V + j * DVS_LD + c0;
-                for (uint64_t mm = l.de[j]; mm;) {                 // the queries that attend j, two per iteration
-                    const int i0 = dvs_ctz64(mm);
-                    mm &= mm - 1;
-                    const bool two = mm != 0;
-                    const int i1 = two ? dvs_ctz64(mm) : i0;
-                    mm &= mm - 1;
-                    const float* q0p = l.Q + i0 * DVS_LD + c0;
-                    const float* q1p = l.Q + i1 * DVS_LD + c0;
-                    const float* g0p = l.DO + i0 * DVS_LD + c0;
-                    const float* g1p = l.DO + i1 * DVS_LD + c0;
-                    // same operand order as phase A (q . k, dO . v): bitwise the same scores
-                    const f4 qa0 = *(const f4*)q0p, qb0 = *(const f4*)(q0p + 4), qa1 = *(const f4*)q1p, qb1 = *(const f4*)(q1p + 4);
-                    const f4 ga0 = *(const f4*)g0p, gb0 = *(const f4*)(g0p + 4), ga1 = *(const f4*)g1p, gb1 = *(const f4*)(g1p + 4);
-                    const float p0 = __expf(dvs_dot8(qa0, qb0, kp) - l.lse[h * DVS_WTOK + i0]);
-                    const float p1 = two ? __expf(dvs_dot8(qa1, qb1, kp) - l.lse[h * DVS_WTOK + i1]) : 0.f;
-                    const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i0) * NTOK + j), D) : 1.0f;
-                    const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i1) * NTOK + j), D) : 1.0f;
-                    const float ds0 = p0 * (mk0 * dvs_dot8(ga0, gb0, vp) - l.delta[h * DVS_WTOK + i0]);
-                    const float ds1 = p1 * (mk1 * dvs_dot8(ga1, gb1, vp) - l.delta[h * DVS_WTOK + i1]);
-                    const float pm0 = p0 * mk0, pm1 = p1 * mk1;
-                    dkr[s][0] += qa0 * ds0 + qa1 * ds1;
-                    dkr[s][1] += qb0 * ds0 + qb1 * ds1;
-                    dvr[s][0] += ga0 * pm0 + ga1 * pm1;
-                    dvr[s][1] += gb0 * pm0 + gb1 * pm1;
+            // merge the two halves of a split row (all lanes execute the exchanges; whole-row lanes ignore them)
+            {
+                const float pm = dvs_pair_xchg(m), pden = dvs_pair_xchg(den), pds = dvs_pair_xchg(dsum);
+                const f4 po0 = dvs_pair_xchg(o0), po1 = dvs_pair_xchg(o1), pa0 = dvs_pair_xchg(a0), pa1 = dvs_pair_xchg(a1);
+                const f4 pb0 = dvs_pair_xchg(b0), pb1 = dvs_pair_xchg(b1);
+                if (it.half >= 0) {
+                    const float M = fmaxf(m, pm);
+                    const float fa = __expf(m - M), fb = __expf(pm - M);
+                    den = den * fa + pden * fb;
+                    dsum = dsum * fa + pds * fb;
+                    o0 = o0 * fa + po0 * fb;
+                    o1 = o1 * fa + po1 * fb;
+                    a0 = a0 * fa + pa0 * fb;
+                    a1 = a1 * fa + pa1 * fb;
+                    b0 = b0 * fa + pb0 * fb;
+                    b1 = b1 * fa + pb1 * fb;
+                    m = M;
                 }
             }
+            if (active && it.half <= 0) {
+                const float rden = 1.0f / den;
+                const float delta = dsum * rden;
+                *(f4*)(l.O + i * DVS_LD + c0) = o0 * rden;
+                *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1 * rden;
+                *(f4*)(l.DQ + i * DVS_LD + c0) = (a0 - b0 * delta) * (rden * scale);
+                *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = (a1 - b1 * delta) * (rden * scale);
+                l.lse[h * DVS_WTOK + i] = m + __logf(den);
+                l.delta[h * DVS_WTOK + i] = delta;
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 1; ++s) {
-            const int item = threadIdx.x;
-            if (item < 8 * N) {
-                const int j = item >> 3, c0 = 8 * (item & 7);
-                *(f4*)(l.K + j * DVS_LD + c0) = dkr[s][0];
-                *(f4*)(l.K + j * DVS_LD + c0 + 4) = dkr[s][1];
-                *(f4*)(l.V + j * DVS_LD + c0) = dvr[s][0];
-                *(f4*)(l.V + j * DVS_LD + c0 + 4) = dvr[s][1];
+        // ---- phase B: (key j, head h), same lane layout (a token's DESCENDANT rows are long for early tokens, so the split
+        //      tokens here are the last ones by index too: the pair split still halves most of the long walks) ---------------
+        f4 dk0 = f4_zero(), dk1 = f4_zero(), dv0 = f4_zero(), dv1 = f4_zero();
+        {
+            const int j = active ? it.tok : 0, h = it.head, c0 = 8 * h;
+            const float* kp = l.K + j * DVS_LD + c0;
+            const float* vp = l.V + j * DVS_LD + c0;
+            for (uint64_t mm = active ? l.de[(it.half + 1) * DVS_WTOK + j] : 0ull; mm;) {   // queries that attend j, two per iteration
+                const int i0 = dvs_ctz64(mm);
+                mm &= mm - 1;
+                const bool two = mm != 0;
+                const int i1 = two ? dvs_ctz64(mm) : i0;
+                mm &= mm - 1;
+                const float* q0p = l.Q + i0 * DVS_LD + c0;
+                const float* q1p = l.Q + i1 * DVS_LD + c0;
+                const float* g0p = l.DO + i0 * DVS_LD + c0;
+                const float* g1p = l.DO + i1 * DVS_LD + c0;
+                // same operand order as phase A (q . k, dO . v): bitwise the same scores
+                const f4 qa0 = *(const f4*)q0p, qb0 = *(const f4*)(q0p + 4), qa1 = *(const f4*)q1p, qb1 = *(const f4*)(q1p + 4);
+                const f4 ga0 = *(const f4*)g0p, gb0 = *(const f4*)(g0p + 4), ga1 = *(const f4*)g1p, gb1 = *(const f4*)(g1p + 4);
+                const float p0 = __expf(dvs_dot8(qa0, qb0, kp) - l.lse[h * DVS_WTOK + i0]);
+                const float p1 = two ? __expf(dvs_dot8(qa1, qb1, kp) - l.lse[h * DVS_WTOK + i1]) : 0.f;
+                const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i0) * NTOK + j), D) : 1.0f;
+                const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i1) * NTOK + j), D) : 1.0f;
+                const float ds0 = p0 * (mk0 * dvs_dot8(ga0, gb0, vp) - l.delta[h * DVS_WTOK + i0]);
+                const float ds1 = p1 * (mk1 * dvs_dot8(ga1, gb1, vp) - l.delta[h * DVS_WTOK + i1]);
+                const float pm0 = p0 * mk0, pm1 = p1 * mk1;
+                dk0 += qa0 * ds0 + qa1 * ds1;
+                dk1 += qb0 * ds0 + qb1 * ds1;
+                dv0 += ga0 * pm0 + ga1 * pm1;
+                dv1 += gb0 * pm0 + gb1 * pm1;
             }
+            const f4 pk0 = dvs_pair_xchg(dk0), pk1 = dvs_pair_xchg(dk1), pv0 = dvs_pair_xchg(dv0), pv1 = dvs_pair_xchg(dv1);
+            if (it.half >= 0) {       // fixed order (even half + odd half) on both lanes: bitwise reproducible
+                dk0 = it.half == 0 ? dk0 + pk0 : pk0 + dk0;
+                dk1 = it.half == 0 ? dk1 + pk1 : pk1 + dk1;
+                dv0 = it.half == 0 ? dv0 + pv0 : pv0 + dv0;
+                dv1 = it.half == 0 ? dv1 + pv1 : pv1 + dv1;
+            }
+        }
+        __syncthreads();
+        if (active && it.half <= 0) {
+            const int j = it.tok, c0 = 8 * it.head;
+            *(f4*)(l.K + j * DVS_LD + c0) = dk0;
+            *(f4*)(l.K + j * DVS_LD + c0 + 4) = dk1;
+            *(f4*)(l.V + j * DVS_LD + c0) = dv0;
+            *(f4*)(l.V + j * DVS_LD + c0 + 4) = dv1;
         }
         __syncthreads();
         if (has_tile) {

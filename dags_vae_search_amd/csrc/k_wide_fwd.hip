@@ -215,6 +215,7 @@ void dvs_launch_embed_fwd_w(const EmbedArgs& a, int grid, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWLds {
     float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *O;
+    uint64_t* rows;              // [3][48]: ancestor bit-rows of the current DAG, their even / odd set bits
 };
 __device__ __forceinline__ AttnWLds attnw_lds(char* smem) {
     AttnWLds l;
@@ -228,9 +229,10 @@ __device__ __forceinline__ AttnWLds attnw_lds(char* smem) {
     l.K = l.Q + DVS_WSCR;
     l.V = l.K + DVS_WSCR;
     l.O = l.V + DVS_WSCR;
+    l.rows = (uint64_t*)(l.O + DVS_WSCR);        // float offset is even: 8-byte aligned
     return l;
 }
-constexpr size_t ATTNW_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR;
+constexpr size_t ATTNW_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR + 6 * DVS_WTOK;
 
 // 8 waves: waves 0..NT-1 own the tiles (MFMA parts), all 8 share the (token, head) items of the core.
 __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
@@ -256,6 +258,15 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
+        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {      // a wave without a tile prepares the rows
+            const int i = threadIdx.x - 256;
+            const uint64_t row = i < N ? rec->allowed[i] : 0ull;
+            uint64_t e, o;
+            dvs_split_row(row, e, o);
+            l.rows[i] = row;
+            l.rows[DVS_WTOK + i] = e;
+            l.rows[2 * DVS_WTOK + i] = o;
+        }
         f4 x[4];
         if (has_tile) {
             f4 kv[4], dummy[4];
@@ -285,16 +296,17 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         }
         __syncthreads();
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        for (int item = threadIdx.x; item < 8 * N; item += blockDim.x) {
-            const int i = item >> 3, h = item & 7;
+        {
+            const DvsCoreItem it = dvs_core_item(N);
+            const bool active = it.tok >= 0;
+            const int i = active ? it.tok : 0, h = it.head;
             const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + 8 * h), q1 = *(const f4*)(l.Q + i * DVS_LD + 8 * h + 4);
-            const uint64_t al = rec->allowed[i];
-            // ONE pass over the ancestor row with an online softmax (running max m, denominator and output rescaled
+            // ONE pass over the (half) ancestor row with an online softmax (running max m, denominator and output rescaled
             // when m grows), two keys per iteration so that their LDS reads overlap: the row walk is latency-bound.
             // Dropout acts on the normalised probabilities; it commutes with the final division by the denominator.
             float m = -3.0e38f, den = 0.f;
             f4 o0 = f4_zero(), o1 = f4_zero();
-            for (uint64_t mm = al; mm;) {
+            for (uint64_t mm = active ? l.rows[(it.half + 1) * DVS_WTOK + i] : 0ull; mm;) {
                 const int j0 = dvs_ctz64(mm);
                 mm &= mm - 1;
                 const bool two = mm != 0;
@@ -316,11 +328,21 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                 o1 = o1 * sc + *(const f4*)(v0 + 4) * e0 + *(const f4*)(v1 + 4) * e1;
                 m = mn;
             }
-            const float rden = 1.0f / den;
-            o0 *= rden;
-            o1 *= rden;
-            *(f4*)(l.O + i * DVS_LD + 8 * h) = o0;
-            *(f4*)(l.O + i * DVS_LD + 8 * h + 4) = o1;
+            // merge the two halves of a split row (all lanes execute the exchange; whole-row lanes ignore it)
+            const float pm = dvs_pair_xchg(m), pden = dvs_pair_xchg(den);
+            const f4 po0 = dvs_pair_xchg(o0), po1 = dvs_pair_xchg(o1);
+            if (it.half >= 0) {
+                const float M = fmaxf(m, pm);
+                const float fa = __expf(m - M), fb = __expf(pm - M);
+                den = den * fa + pden * fb;
+                o0 = o0 * fa + po0 * fb;
+                o1 = o1 * fa + po1 * fb;
+            }
+            if (active && it.half <= 0) {
+                const float rden = 1.0f / den;
+                *(f4*)(l.O + i * DVS_LD + 8 * h) = o0 * rden;
+                *(f4*)(l.O + i * DVS_LD + 8 * h + 4) = o1 * rden;
+            }
         }
         __syncthreads();
         if (has_tile) {

@@ -123,3 +123,27 @@ def test_emu_batch_sharding_is_additive():
         lsum += float(l[0])
     assert rel(lsum, la[0]) < 1e-6
     assert np.abs(tot - fa).max() < 1e-5 * max(1.0, np.abs(fa).max())
+
+
+@pytest.mark.parametrize("n,card,B,train", [(1, 1, 3, False), (2, 5, 2, True), (13, 13, 3, True), (14, 14, 2, True),
+                                            (13, 14, 2, False), (20, 3, 2, True), (45, 45, 2, False)])
+def test_emu_edge_sizes_forward_and_gradients(n, card, B, train):
+    """Size edges of the path: the smallest graph (N = 4 tokens), the one-tile limit (N = 16), the smallest tiled shape
+    (N = 17), a shape that is wide only by its class count (C = 17), two tiles with few classes, and the maximum
+    (N = C = 48) — loss and all 108 gradients against the oracle (fresh-seed parameters), dropout on where marked."""
+    cfg = po.PaceConfig(n=n, card=card)
+    params = po.init_params(cfg, seed=5)
+    graphs = ofeat.synthetic_dags(n, card, B, seed=3, density_limit=0.2 if n > 20 else 0.4)
+    f_np = ofeat.dense_features(graphs, card)
+    m = EmuModel(cfg, {k: v.numpy() for k, v in params.items()}, B, training=train, dropout=0.15, seed=77, dag_offset=5)
+    assert m.pack(f_np) == 0
+    losses, _, _ = m.forward()
+    grads, flat = m.backward(1.0, 0.005)
+    assert not np.isnan(flat).any()
+    kw = {}
+    if train:
+        masks = DeviceMasks(77, 0.15, dag_offset=5)
+        kw = dict(training=True, eps=torch.from_numpy(masks.eps(B)), masks=masks)
+    total, recon, kld, ref = _oracle_grads(cfg, params, f_np, **kw)
+    assert rel(losses[0], total) < 1e-4 and rel(losses[2], kld) < 1e-4
+    _check_grads(grads, ref, 1e-3)

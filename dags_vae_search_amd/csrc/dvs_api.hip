@@ -7,6 +7,7 @@
 #include "dvs_kernels.h"
 #include "dvs_backward.h"
 #include "dvs_wide.h"
+#include "dvs_wimg.h"
 
 static thread_local char g_err[256] = "";
 
@@ -210,6 +211,7 @@ DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab) {
     w.nslab = nslab;
     w.slabs = take((size_t)nslab * (size_t)P);
     w.fcpart = take((size_t)DVS_FC_PARTS * (size_t)P);
+    w.wimg = take((DVS_WIMG_BF16 + 1) / 2);
     w.total_floats = off;
     return w;
 }
@@ -341,6 +343,59 @@ static inline int slot_dec(int layer, int sub) { return 8 + 3 * layer + sub; }  
 static inline int site_enc(int layer, int k) { return 4 + 4 * layer + k; }
 static inline int site_dec(int layer, int k) { return 16 + 6 * layer + k; }
 
+// ---- per-step weight images (dvs_wimg.h) ------------------------------------------------------------------------------
+static inline size_t img_attn(int block) { return (size_t)block * DvsAttnImg::SIZE; }                       // 0..8
+static inline size_t img_ffn(int block) { return DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + (size_t)block * DvsFfnImg::SIZE; }   // 0..5
+static inline int blk_enc_attn(int layer) { return layer; }
+static inline int blk_dec_self(int layer) { return 3 + 2 * layer; }
+static inline int blk_dec_cross(int layer) { return 4 + 2 * layer; }
+static inline int blk_enc_ffn(int layer) { return layer; }
+static inline int blk_dec_ffn(int layer) { return 3 + layer; }
+
+static void prepare_images(const DvsLayout& L, bool wide, const float* params, float* ws, const DvsWorkspace& W,
+                           dvs_stream_t st) {
+    DvsImgJobs J;
+    J.count = 0;
+    auto add = [&](int64_t src, size_t dst, int rows, int flags) {
+        DvsImgJob& j = J.job[J.count++];
+        j.src = src;
+        j.dst = (int64_t)dst;
+        j.rows = rows;
+        j.flags = flags;
+    };
+    auto attn = [&](const DvsAttnP& p, int block) {
+        const size_t b = img_attn(block);
+        if (!wide) {             // the wide attention kernels keep fp32 images of their own
+            add(p.in_w, b + DvsAttnImg::Win, 192, 2);                 // x6, rows in slot order
+            add(p.out_w, b + DvsAttnImg::Wout, 64, 4);                // x6, columns in slot order
+            add(p.out_w, b + DvsAttnImg::WoutT, 64, 1 | 4);           // x3 transposed, image rows in slot order
+        }
+        for (int q = 0; q < 3; ++q)                                    // W_q^T, W_k^T, W_v^T for k_proj_bwd
+            add(p.in_w + 4096 * q, b + DvsAttnImg::WinT + (size_t)q * 2 * DVS_IMG64, 64, 1 | (wide ? 0 : 2));
+    };
+    auto ffn = [&](const DvsFfnP& p, int block) {
+        const size_t b = img_ffn(block);
+        add(p.l1_w, b + DvsFfnImg::W1, 64, 0);
+        add(p.l2_w, b + DvsFfnImg::W2, 64, 0);
+        add(p.l2_w, b + DvsFfnImg::W2T, 64, 1);
+        add(p.l1_w, b + DvsFfnImg::W1T, 64, 1);
+    };
+    for (int i = 0; i < DVS_LAYERS; ++i) {
+        attn(L.enc[i].sa, blk_enc_attn(i));
+        ffn(L.enc[i].ff, blk_enc_ffn(i));
+        attn(L.dec[i].sa, blk_dec_self(i));
+        attn(L.dec[i].ca, blk_dec_cross(i));
+        ffn(L.dec[i].ff, blk_dec_ffn(i));
+    }
+    dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), st);
+}
+static inline const void* wimg_attn(const float* ws, const DvsWorkspace& W, int block) {
+    return (const dvs_bf16*)(ws + W.wimg) + img_attn(block);
+}
+static inline const void* wimg_ffn(const float* ws, const DvsWorkspace& W, int block) {
+    return (const dvs_bf16*)(ws + W.wimg) + img_ffn(block);
+}
+
 // launch grids of the forward kernels
 struct FwdGrids {
     bool wide;
@@ -396,6 +451,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.in_b = P + L.enc[i].sa.in_b;
         a.out_w = P + L.enc[i].sa.out_w;
         a.out_b = P + L.enc[i].sa.out_b;
+        a.wimg = wimg_attn(ws, W, blk_enc_attn(i));
         const int sa = slot_enc(i, 0);
         a.out_pre = ws + W.act[sa];
         a.out_stats = ws + W.stats[sa];
@@ -411,6 +467,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         f.l1_b = P + L.enc[i].ff.l1_b;
         f.l2_w = P + L.enc[i].ff.l2_w;
         f.l2_b = P + L.enc[i].ff.l2_b;
+        f.wimg = wimg_ffn(ws, W, blk_enc_ffn(i));
         const int sf = slot_enc(i, 1);
         f.out_pre = ws + W.act[sf];
         f.out_stats = ws + W.stats[sf];
@@ -487,6 +544,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.in_b = params + pl.sa.in_b;
         a.out_w = params + pl.sa.out_w;
         a.out_b = params + pl.sa.out_b;
+        a.wimg = wimg_attn(ws, W, blk_dec_self(i));
         const int s0 = slot_dec(i, 0);
         a.out_pre = ws + W.act[s0];
         a.out_stats = ws + W.stats[s0];
@@ -505,6 +563,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         c.in_b = params + pl.ca.in_b;
         c.out_w = params + pl.ca.out_w;
         c.out_b = params + pl.ca.out_b;
+        c.wimg = wimg_attn(ws, W, blk_dec_cross(i));
         const int s1 = slot_dec(i, 1);
         c.out_pre = ws + W.act[s1];
         c.out_stats = ws + W.stats[s1];
@@ -521,6 +580,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         f.l1_b = params + pl.ff.l1_b;
         f.l2_w = params + pl.ff.l2_w;
         f.l2_b = params + pl.ff.l2_b;
+        f.wimg = wimg_ffn(ws, W, blk_dec_ffn(i));
         const int s2 = slot_dec(i, 2);
         f.out_pre = ws + W.act[s2];
         f.out_stats = ws + W.stats[s2];
@@ -544,6 +604,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
     dvs_stream_t st = (dvs_stream_t)stream;
     const FwdGrids grid = fwd_grids(d, is_wide(s));
 
+    prepare_images(L, grid.wide, params, ws, W, st);
     encoder_forward(d, L, W, rec, params, ws, grid, st);
     dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
 
@@ -593,6 +654,7 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* 
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
+    prepare_images(L, is_wide(s), params, ws, W, st);
     encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st);
     LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
     la.dims.training = 0;
@@ -625,6 +687,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, void* workspa
     const FwdGrids grid = fwd_grids(d, wide);
     const DvsRecord* rec = (const DvsRecord*)records;
 
+    prepare_images(L, wide, params, ws, W, st);
     dvs_launch_decode_memory(d, z, params + L.fc3_w, params + L.fc3_b, ws + W.mem, st);
     DecodeArgs a;
     memset(&a, 0, sizeof(a));

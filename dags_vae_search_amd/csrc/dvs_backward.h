@@ -13,6 +13,7 @@ struct FfnBwdArgs {
     const float* xin;            // pre-sum feeding this sublayer (or embedding output)
     DvsLN ln;                    // LayerNorm of the producing sublayer (stats null = none)
     const float *l1_w, *l1_b, *l2_w, *l2_b;
+    const void* wimg;            // this sublayer's FFN image block (dvs_wimg.h)
     const float* gpre;           // d(pre of this sublayer)  — or d(LayerNorm(pre)) when `own` is set
     // optional: the incoming gradient is w.r.t. LN_own(pre_own); pull it back through that LayerNorm first
     const float* own_pre;
@@ -29,6 +30,7 @@ struct ProjBwdArgs {             // backward of 1..3 stacked 64->64 projections 
     const float* xin;
     DvsLN ln;                    // stats null: X is used as is (embedding output or decoder memory)
     const float* w;              // first row of the stacked weight block [64*NPROJ][64]
+    const void* wimg;            // W_p^T image pairs of these projections (dvs_wimg.h: DvsAttnImg::WinT + 2 p0 DVS_IMG64)
     const float* gy[3];          // d(projection outputs), T-layout frag tiles
     const float* gres;           // optional residual gradient added to dX before the LayerNorm backward
     float* gout;                 // result: d(pre of producer) / d(X)
@@ -46,6 +48,7 @@ struct AttnBwdArgs {
     DvsLN ln;
     const float* kv;             // null = self-attention
     const float *in_w, *in_b, *out_w, *out_b;
+    const void* wimg;            // this sublayer's attention image block (dvs_wimg.h); one-tile path
     const float* gpre;           // d(pre of this sublayer)
     float *gq, *gk, *gv;         // outputs: d(q), d(k), d(v) projections (T-layout frag tiles)
     int site_prob, site_post;

@@ -45,6 +45,7 @@ struct AttnArgs {
     DvsLN ln;                    // LayerNorm of the producing sublayer
     const float* kv;             // null: self-attention; else decoder memory [B][1024] (no LayerNorm)
     const float *in_w, *in_b, *out_w, *out_b;
+    const void* wimg;            // this sublayer's attention image block (dvs_wimg.h); one-tile path
     float* out_pre;              // x + dropout(attn(x))
     float* out_stats;
     int site_prob, site_post;
@@ -55,6 +56,7 @@ struct FfnArgs {
     const float* xin;
     DvsLN ln;
     const float *l1_w, *l1_b, *l2_w, *l2_b;
+    const void* wimg;            // this sublayer's FFN image block (dvs_wimg.h)
     float* out_pre;
     float* out_stats;
     float* out_norm;             // optional: LayerNorm(out_pre) with (ng, nb) — encoder output for fc1/fc2

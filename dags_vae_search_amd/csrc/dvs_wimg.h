@@ -1,0 +1,55 @@
+// Per-step weight images (the LDS images of dvs_bf16.h, built ONCE per step in global memory).
+//
+// Every sublayer kernel used to convert its weights on entry: fp32 -> bf16 parts, column permutation, element-wise
+// 2-byte LDS stores — 10-15 us of every launch, with only 16 DAGs per workgroup to amortise it (a batch of 8 DAGs ran
+// k_attn_fwd in 24 us against 34 us for 4096).  Parameters change once per step, so k_prepare_images writes, for every
+// attention and FFN sublayer, the images exactly as the kernels want them in LDS; staging is then a 16-byte-per-lane
+// copy (dvs_copy_image).  Blocks live in the caller's workspace (DvsWorkspace::wimg), bf16 units below.
+//
+//   attention block : Win  x6 [3][192][LDB]  rows in slot order         (k_attn_fwd; parts 0,1 = the x3 pair of k_attn_bwd)
+//                     Wout x6 [3][ 64][LDB]  columns in slot order      (k_attn_fwd)
+//                     WoutT x3 [2][64][LDB]  image rows in slot order   (k_attn_bwd: dO^T = Wo^T dy^T)
+//                     WinT  x3 [3 proj][2][64][LDB]                     (k_proj_bwd: dX^T = W_p^T dY_p^T)
+//   FFN block       : W1 x6 [3][64][LDB], W2 x6 [3][64][LDB]            (k_ffn_fwd; W1 also k_ffn_bwd's hidden recompute)
+//                     W2T x3 [2][64][LDB], W1T x3 [2][64][LDB]          (k_ffn_bwd)
+#pragma once
+#include "dvs_bf16.h"
+
+constexpr size_t DVS_IMG64 = 64 * (size_t)DVS_LDB;            // one 64-row image
+struct DvsAttnImg {
+    static constexpr size_t Win = 0;
+    static constexpr size_t Wout = 3 * 3 * DVS_IMG64;
+    static constexpr size_t WoutT = Wout + 3 * DVS_IMG64;
+    static constexpr size_t WinT = WoutT + 2 * DVS_IMG64;
+    static constexpr size_t SIZE = WinT + 3 * 2 * DVS_IMG64;
+};
+struct DvsFfnImg {
+    static constexpr size_t W1 = 0;
+    static constexpr size_t W2 = 3 * DVS_IMG64;
+    static constexpr size_t W2T = 6 * DVS_IMG64;
+    static constexpr size_t W1T = 8 * DVS_IMG64;
+    static constexpr size_t SIZE = 10 * DVS_IMG64;
+};
+// blocks of one step: encoder layer i -> attention block 3i ... see dvs_api.hip (img_enc_attn etc.)
+constexpr int DVS_N_ATTN_BLOCKS = 9, DVS_N_FFN_BLOCKS = 6;
+constexpr size_t DVS_WIMG_BF16 = DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + DVS_N_FFN_BLOCKS * DvsFfnImg::SIZE;
+
+struct DvsImgJob {
+    int64_t src;                 // float offset of the matrix in the flat parameter buffer
+    int64_t dst;                 // bf16 offset of the image (first part) in the image buffer
+    int32_t rows;                // source rows (64 columns)
+    int32_t flags;               // bit 0: transposed x3 (else x6 rows); bit 1: rperm; bit 2: cperm
+};
+constexpr int DVS_MAX_IMG_JOBS = 96;
+struct DvsImgJobs {
+    DvsImgJob job[DVS_MAX_IMG_JOBS];
+    int count;
+};
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, dvs_stream_t st);
+
+// LDS <- global image copy, 16 bytes per lane (n = bf16 count, a multiple of 8; both 16-byte aligned)
+__device__ __forceinline__ void dvs_copy_image(dvs_bf16* dst, const dvs_bf16* __restrict__ src, int n) {
+    const f4* s = (const f4*)src;
+    f4* d = (f4*)dst;
+    for (int i = threadIdx.x; i < (n >> 3); i += blockDim.x) d[i] = s[i];
+}

@@ -1,6 +1,6 @@
 // Backward kernels: FFN sublayer, stacked-projection (q/k/v) backward with fused LayerNorm backward, slab reduce.
 #include "dvs_backward.h"
-#include "dvs_bf16.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // FFN sublayer backward (autograd of pace.py:62-65 / 151-153).  Recomputes h = drop(relu(W1 x + b1)) from the saved
@@ -41,9 +41,8 @@ static size_t ffnb_lds_bytes() {
 __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const FfnBLds l = ffnb_lds(smem);
-    dvs_stage_bf3(l.W1x6, a.l1_w, 64, 64);
-    dvs_stage_bf_t(l.W2Th, l.W2Tl, a.l2_w, 64, 64);
-    dvs_stage_bf_t(l.W1Th, l.W1Tl, a.l1_w, 64, 64);
+    dvs_copy_image(l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
+    dvs_copy_image(l.W1x6, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(3 * DVS_IMG64));
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {
@@ -189,15 +188,12 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
     DVS_DYN_LDS(smem);
     // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
     // of the forward depends on it), so it runs on the bf16 matrix pipe; the weight gradients stay exact fp32.
-    dvs_bf16* WTh = (dvs_bf16*)smem;               // [NPROJ][64][LDB]
-    dvs_bf16* WTl = WTh + NPROJ * 64 * DVS_LDB;
-    float* lg = (float*)(WTl + NPROJ * 64 * DVS_LDB);
+    dvs_bf16* WT = (dvs_bf16*)smem;                // [NPROJ][hi | lo][64][LDB]
+    float* lg = (float*)(WT + NPROJ * 2 * DVS_IMG64);
     float* lb = lg + 64;
     float* slots = lb + 64;                        // per wave 3 tiles: A0, A1 (alternating dY) and B (X)
     int* gcount = (int*)(slots + 8 * 3 * DVS_SCR);
-#pragma unroll
-    for (int p = 0; p < NPROJ; ++p)
-        dvs_stage_bf_t(WTh + p * 64 * DVS_LDB, WTl + p * 64 * DVS_LDB, a.w + (size_t)p * 4096, 64, 64, a.slot_order != 0);
+    dvs_copy_image(WT, (const dvs_bf16*)a.wimg, (int)(NPROJ * 2 * DVS_IMG64));
     if (a.ln.stats) {
         dvs_stage_vector(lg, a.ln.g, 64);
         dvs_stage_vector(lb, a.ln.b, 64);
@@ -243,7 +239,7 @@ __global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
             vb[p] += dvs_colsum(mine, L);
             dvs_group_barrier(G, L);
             dvs_coop_dw(aW[p], slots + (p & 1) * DVS_SCR, slots + 2 * DVS_SCR, 3 * DVS_SCR, L);
-            dvs_matb_T<4>(dx, dvs_split_T(dy), WTh + p * 64 * DVS_LDB, WTl + p * 64 * DVS_LDB, 0, L);
+            dvs_matb_T<4>(dx, dvs_split_T(dy), WT + p * 2 * DVS_IMG64, WT + p * 2 * DVS_IMG64 + DVS_IMG64, 0, L);
         }
         dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
         if (a.ln.stats) {

@@ -8,7 +8,7 @@
 // q,k (T-layout) feed the score products directly; their N-layout copies (for dq/dk), v^T and dO (N) come from
 // per-wave LDS transposes.
 #include "dvs_backward.h"
-#include "dvs_bf16.h"
+#include "dvs_wimg.h"
 
 struct AttnBLds {
     float *inb, *outb, *lg, *lb, *slots, *stats;
@@ -67,8 +67,8 @@ __device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, cons
 __global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnBLds l = attnb_lds(smem);
-    dvs_stage_bf(l.Winh, l.Winl, a.in_w, 64, 192, true, false);                // head-aligned slot order (dvs_device.h)
-    dvs_stage_bf_t(l.WoTh, l.WoTl, a.out_w, 64, 64, false, true);       // image rows = O's slot order
+    dvs_copy_image(l.Winh, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, 2 * 192 * DVS_LDB);   // parts hi, mid of the x6 triple = the x3 pair
+    dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));
     dvs_stage_vector_perm(l.inb, a.in_b, 192);
     dvs_stage_vector(l.outb, a.out_b, 64);
     if (a.ln.stats) {

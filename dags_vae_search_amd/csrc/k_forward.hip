@@ -1,7 +1,7 @@
 // Forward kernels of the PACE-VAE step: feature packing, embeddings, attention sublayer, FFN sublayer.
 // One wave owns one DAG (see dvs_device.h); workgroups are persistent and keep the sublayer's weights in LDS.
 #include "dvs_kernels.h"
-#include "dvs_bf16.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // dvs_pack_features: reference-layout dense features -> 96-byte records (replaces pace.py:1981-1985's
@@ -281,10 +281,10 @@ __device__ __forceinline__ AttnLds attn_lds(char* smem) {
 }
 static size_t attn_lds_bytes() { return 3 * 256 * DVS_LDB * sizeof(dvs_bf16) + (192 + 64 + 128) * sizeof(float); }
 
-__device__ __forceinline__ void attn_stage(const AttnLds& l, const float* in_w, const float* in_b, const float* out_w,
-                                           const float* out_b, const DvsLN& ln) {
-    dvs_stage_bf3(l.Win, in_w, 64, 192, true, false);      // rows -> head-aligned slot order
-    dvs_stage_bf3(l.Wout, out_w, 64, 64, false, true);     // columns likewise
+__device__ __forceinline__ void attn_stage(const AttnLds& l, const void* wimg, const float* in_b, const float* out_b,
+                                           const DvsLN& ln) {
+    // Win (rows in head-aligned slot order) and Wout (columns likewise) as ready-made bf16x6 images: one straight copy
+    dvs_copy_image(l.Win, (const dvs_bf16*)wimg + DvsAttnImg::Win, (int)(DvsAttnImg::WoutT - DvsAttnImg::Win));
     dvs_stage_vector_perm(l.inb, in_b, 192);
     dvs_stage_vector(l.outb, out_b, 64);
     if (ln.stats) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
 __global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
     DVS_DYN_LDS(smem);
     const AttnLds l = attn_lds(smem);
-    attn_stage(l, a.in_w, a.in_b, a.out_w, a.out_b, a.ln);
+    attn_stage(l, a.wimg, a.in_b, a.out_b, a.ln);
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -468,8 +468,7 @@ static size_t ffn_lds_bytes() { return 6 * 64 * DVS_LDB * sizeof(dvs_bf16) + 6 *
 __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
     DVS_DYN_LDS(smem);
     const FfnLds l = ffn_lds(smem);
-    dvs_stage_bf3(l.W1, a.l1_w, 64, 64);
-    dvs_stage_bf3(l.W2, a.l2_w, 64, 64);
+    dvs_copy_image(l.W1, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(6 * DVS_IMG64));     // W1, W2 bf16x6 images
     dvs_stage_vector(l.b1, a.l1_b, 64);
     dvs_stage_vector(l.b2, a.l2_b, 64);
     if (a.ln.stats) {

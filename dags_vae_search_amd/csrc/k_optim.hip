@@ -67,3 +67,38 @@ void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, floa
     DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
                        bc1, sqrtf(bc2), (const float*)scratch);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-step weight images (dvs_wimg.h): one workgroup per (job, 16-row slice).
+// ---------------------------------------------------------------------------------------------------------
+#include "dvs_wimg.h"
+__global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg) {
+    const int jb = blockIdx.x / 12, slice = blockIdx.x % 12;         // up to 192 rows = 12 slices of 16
+    if (jb >= jobs.count) return;
+    const DvsImgJob J = jobs.job[jb];
+    const bool transposed = J.flags & 1, rperm = J.flags & 2, cperm = J.flags & 4;
+    const float* src = params + J.src;
+    dvs_bf16* dst = wimg + J.dst;
+    for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) {
+        const int row = 16 * slice + (i >> 6), col = i & 63;
+        if (row >= J.rows) break;
+        const float v = src[(size_t)(rperm ? dvs_pi(row) : row) * 64 + (cperm ? dvs_pi(col) : col)];
+        if (!transposed) {                       // x6: [3][rows][LDB], img[row][kperm(col)]
+            dvs_bf16 h, m, l;
+            dvs_split3_1(v, h, m, l);
+            const size_t o = (size_t)row * DVS_LDB + dvs_kperm(col), part = (size_t)J.rows * DVS_LDB;
+            dst[o] = h;
+            dst[part + o] = m;
+            dst[2 * part + o] = l;
+        } else {                                 // x3 transposed: [2][64][LDB], img[col][kperm(row)]
+            dvs_bf16 h, l;
+            dvs_split1(v, h, l);
+            const size_t o = (size_t)col * DVS_LDB + dvs_kperm(row);
+            dst[o] = h;
+            dst[DVS_IMG64 + o] = l;
+        }
+    }
+}
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, dvs_stream_t st) {
+    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12), dim3(256), 0, st, jobs, params, wimg);
+}

@@ -372,15 +372,16 @@ void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int
 // Latent block backward, part 1 (one wave per 16 DAGs): dz^T = fc3^T dmem^T; through the reparameterisation and
 // the KL term to (d mu, d logvar); then d enc_out^T = [fc1;fc2]^T [dmu;dlogvar]^T, stored frag order.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
-    __shared__ f4 part[4][2][64];
+constexpr int LATB_WAVES = 16;   // as k_latent_fwd: a latency-bound chunk walk spread over 16 waves per 16-DAG group
+__global__ __launch_bounds__(64 * LATB_WAVES) void k_latent_bwd(LatentBwdArgs a) {
+    __shared__ f4 part[LATB_WAVES][2][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
     const int ldw = N * 64;
     const float gkl = a.gcoef[1];
     const int dag = blockIdx.x * 16 + L.r;
     const bool dvalid = dag < B;
-    const int NT = a.dims.NT, mch = 16 * NT;          // chunk m: tile m >> 6, chunk m & 63 of it (k_latent_fwd)
+    const int NT = a.dims.NT, mch = 64 * NT / LATB_WAVES;   // chunk m: tile m >> 6, chunk m & 63 of it (k_latent_fwd)
     const size_t dstride = (size_t)NT * DVS_TILE;
     const int m0 = mch * L.wave;
     f4 dz[2] = {f4_zero(), f4_zero()};
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
     for (int t = 0; t < 2; ++t) {
         dz[t] = part[0][t][L.lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) dz[t] += part[w][t][L.lane];
+        for (int w = 1; w < LATB_WAVES; ++w) dz[t] += part[w][t][L.lane];
     }
     // dz[t][reg] = d z[o = 16t + 4g + reg][dag r]
     f4 dout[4];
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
-    DVS_LAUNCH(k_latent_bwd, dim3(ngroups), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_latent_bwd, dim3(ngroups), dim3(64 * LATB_WAVES), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

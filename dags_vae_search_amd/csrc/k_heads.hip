@@ -17,8 +17,10 @@ __device__ __forceinline__ float dvs_normal(uint32_t key, uint32_t e) {
 
 // One workgroup (4 waves) per group of 16 DAGs: the contraction (fc1/fc2) and the output rows (fc3) are split over the
 // waves by 16-float chunk index m; the fc1/fc2 partial sums meet in LDS and are added in wave order.
-__global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
-    __shared__ f4 part[4][4][64];
+constexpr int LAT_WAVES = 8;     // waves per 16-DAG group: a serial, latency-bound chunk walk (measured: 4 waves 37 us, 8 waves 31 us, 16 waves 45 us)
+__global__ __launch_bounds__(64 * LAT_WAVES) void k_latent_fwd(LatentArgs a) {
+    DVS_DYN_LDS(smem);
+    f4 (*part)[4][64] = (f4 (*)[4][64])smem;            // [LAT_WAVES][4][64]
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
     const int ldw = N * 64;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
     const bool dvalid = dag < B;
     f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     // chunk m of the DAG's NT frag-order tiles: tile m >> 6, 16-float chunk mm = m & 63 of that tile
-    const int NT = a.dims.NT, mch = 16 * NT;
+    const int NT = a.dims.NT, mch = 64 * NT / LAT_WAVES;
     const size_t dstride = (size_t)NT * DVS_TILE;
     const int m0 = mch * L.wave;
 #pragma unroll 4
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
     for (int ot = 0; ot < 4; ++ot) {
         acc[ot] = *(const f4*)((ot < 2 ? a.fc1_b + 16 * ot : a.fc2_b + 16 * (ot - 2)) + 4 * L.g);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc[ot] += part[w][ot][L.lane];
+        for (int w = 0; w < LAT_WAVES; ++w) acc[ot] += part[w][ot][L.lane];
     }
     // acc[ot][reg] = out[o = 16(ot&1) + 4g + reg][dag r]; ot 0,1 = mu, ot 2,3 = logvar
     float kl = 0.f;
@@ -112,7 +114,9 @@ __global__ __launch_bounds__(256) void k_latent_fwd(LatentArgs a) {
 
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st) {
     const int ngroups = (a.dims.B + 15) / 16;
-    DVS_LAUNCH(k_latent_fwd, dim3(ngroups), dim3(256), 0, st, a);
+    const size_t lds = (size_t)LAT_WAVES * 4 * 64 * sizeof(f4);
+    DVS_SET_LDS(k_latent_fwd, lds);
+    DVS_LAUNCH(k_latent_fwd, dim3(ngroups), dim3(64 * LAT_WAVES), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -92,10 +92,31 @@ __device__ __forceinline__ f4 f4_splat(float v) { return f4{v, v, v, v}; }
 // copy a row-major [rows][cols] global matrix (leading dimension ldg) into an LDS image with stride ldl
 __device__ __forceinline__ void dvs_stage_matrix(float* dst, int ldl, const float* __restrict__ src, int ldg, int rows,
                                                  int cols) {
-    const int c4 = cols >> 2;
-    for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
-        const int row = i / c4, c = (i - row * c4) << 2;
-        *(f4*)(dst + row * ldl + c) = *(const f4*)(src + (size_t)row * ldg + c);   // all sources are 16-byte aligned
+    // Loads in batches of 4 per thread before the first store (a load -> store loop pays one L2 round trip per iteration),
+    // and every workgroup starts at a different element: all workgroups of a launch read the same matrix at the same time
+    // and would otherwise queue on the same L2 lines (measured on the bf16 images: +5 % DAGs/s).
+    const int c4 = cols >> 2, n = rows * c4, step = blockDim.x;
+    const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n);
+    int i = threadIdx.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+        f4 v[4];
+        int off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int j = i + u * step + rot;
+            j = j >= n ? j - n : j;
+            const int row = j / c4, c = (j - row * c4) << 2;
+            v[u] = *(const f4*)(src + (size_t)row * ldg + c);   // all sources are 16-byte aligned
+            off[u] = row * ldl + c;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(f4*)(dst + off[u]) = v[u];
+    }
+    for (; i < n; i += step) {
+        int j = i + rot;
+        j = j >= n ? j - n : j;
+        const int row = j / c4, c = (j - row * c4) << 2;
+        *(f4*)(dst + row * ldl + c) = *(const f4*)(src + (size_t)row * ldg + c);
     }
 }
 __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __restrict__ src, int n) {

@@ -47,9 +47,32 @@ struct DvsImgJobs {
 };
 void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, dvs_stream_t st);
 
-// LDS <- global image copy, 16 bytes per lane (n = bf16 count, a multiple of 8; both 16-byte aligned)
+// LDS <- global image copy, 16 bytes per lane (n = bf16 count, a multiple of 8; both 16-byte aligned).  Loads are issued
+// in batches of 8 per thread before the first store: a load -> store loop pays one full L2 round trip per iteration
+// (measured: 15.4 k cycles for 64 KB on 512 threads, 20 % of k_ffn_bwd).
 __device__ __forceinline__ void dvs_copy_image(dvs_bf16* dst, const dvs_bf16* __restrict__ src, int n) {
     const f4* s = (const f4*)src;
     f4* d = (f4*)dst;
-    for (int i = threadIdx.x; i < (n >> 3); i += blockDim.x) d[i] = s[i];
+    const int n16 = n >> 3, step = blockDim.x;
+    // every workgroup of the launch copies the SAME image at the same time: start each one at a different offset so that
+    // they do not all queue on the same L2 lines
+    const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n16);
+    int i = threadIdx.x;
+    for (; i + 7 * step < n16; i += 8 * step) {
+        f4 v[8];
+        int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            j[u] = i + u * step + rot;
+            j[u] = j[u] >= n16 ? j[u] - n16 : j[u];
+            v[u] = s[j[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[j[u]] = v[u];
+    }
+    for (; i < n16; i += step) {
+        int j = i + rot;
+        j = j >= n16 ? j - n16 : j;
+        d[j] = s[j];
+    }
 }

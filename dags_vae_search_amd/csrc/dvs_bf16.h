@@ -9,8 +9,8 @@
 // Operand layout: lane l = 16g + r supplies 8 consecutive k of row/column r.  Any k-permutation is allowed as long as A
 // and B use the same one, so a K = 32 block is the tile pair (2p, 2p+1) of the T-layout: k = 8g + 4(t&1) + kk  <->
 // feature 16t + 4g + kk.  An activation tile therefore splits register-locally (dvs_split_T), and weight images are
-// stored in LDS as bf16 [rows][DVS_LDB] with their columns in that order (dvs_kperm), hi and lo separately: a lane's
-// fragment is one 16-byte read.  The accumulator layout is that of the f32 16x16 MFMA, so results chain unchanged.
+// bf16 [rows][DVS_LDB] with their columns in that order (dvs_kperm), hi and lo separately (built once per step by
+// k_prepare_images, dvs_wimg.h, and copied into LDS): a lane's fragment is one 16-byte read.  The accumulator layout is that of the f32 16x16 MFMA, so results chain unchanged.
 #pragma once
 #include "dvs_device.h"
 
@@ -52,31 +52,6 @@ __device__ __forceinline__ SplitT dvs_split_T(const f4 (&x)[4]) {
     dvs_split8(x[0], x[1], s.hi[0], s.lo[0]);
     dvs_split8(x[2], x[3], s.hi[1], s.lo[1]);
     return s;
-}
-
-// LDS images of a row-major [rows][64] fp32 matrix (leading dimension ldg): img[row][dvs_kperm(col)], hi and lo.
-// rperm / cperm: the image's rows / columns are in the attention slot order (dvs_pi, dvs_device.h).
-__device__ __forceinline__ void dvs_stage_bf(dvs_bf16* hi, dvs_bf16* lo, const float* __restrict__ src, int ldg, int rows,
-                                             bool rperm = false, bool cperm = false) {
-    for (int i = threadIdx.x; i < rows * 64; i += blockDim.x) {
-        const int row = i >> 6, col = i & 63;
-        dvs_bf16 h, l;
-        dvs_split1(src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)], h, l);
-        hi[row * DVS_LDB + dvs_kperm(col)] = h;
-        lo[row * DVS_LDB + dvs_kperm(col)] = l;
-    }
-}
-// transposed images: img[col][dvs_kperm(row)] (column fragments for dX^T = W^T dY^T); rperm / cperm: the source's rows
-// (= the k index) / columns (= the image rows) are taken in attention slot order
-__device__ __forceinline__ void dvs_stage_bf_t(dvs_bf16* hi, dvs_bf16* lo, const float* __restrict__ src, int ldg, int rows,
-                                               bool rperm = false, bool cperm = false) {
-    for (int i = threadIdx.x; i < rows * 64; i += blockDim.x) {
-        const int row = i >> 6, col = i & 63;
-        dvs_bf16 h, l;
-        dvs_split1(src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)], h, l);
-        hi[col * DVS_LDB + dvs_kperm(row)] = h;
-        lo[col * DVS_LDB + dvs_kperm(row)] = l;
-    }
 }
 
 __device__ __forceinline__ bf8 dvs_wfrag(const dvs_bf16* img, int row, int p, const Lane& L) {
@@ -158,22 +133,7 @@ __device__ __forceinline__ Split3T dvs_split3_T(const f4 (&x)[4]) {
         }
     return s;
 }
-// three images (hi, mid, lo) of rows*DVS_LDB bf16 each, consecutive at img
-__device__ __forceinline__ void dvs_stage_bf3(dvs_bf16* img, const float* __restrict__ src, int ldg, int rows, bool rperm = false,
-                                              bool cperm = false) {
-    dvs_bf16* mid = img + rows * DVS_LDB;
-    dvs_bf16* lo = mid + rows * DVS_LDB;
-    for (int i = threadIdx.x; i < rows * 64; i += blockDim.x) {
-        const int row = i >> 6, col = i & 63;
-        dvs_bf16 h, m, l;
-        dvs_split3_1(src[(size_t)(rperm ? dvs_pi(row) : row) * ldg + (cperm ? dvs_pi(col) : col)], h, m, l);
-        const int o = row * DVS_LDB + dvs_kperm(col);
-        img[o] = h;
-        mid[o] = m;
-        lo[o] = l;
-    }
-}
-// y^T[OT] (T) += W[row0 + 16*OT rows][64] * x^T, W given as the three images of dvs_stage_bf3 (`rows` rows each)
+// y^T[OT] (T) += W[row0 + 16*OT rows][64] * x^T, W given as an image triple [hi | mid | lo][rows][DVS_LDB] (dvs_wimg.h)
 template <int OT, bool N_LAYOUT = false>
 __device__ __forceinline__ void dvs_matb3(f4 (&y)[OT], const Split3T& x, const dvs_bf16* img, int rows, int row0, const Lane& L) {
     const dvs_bf16* Wh = img;

@@ -60,6 +60,9 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_bic_scores.restype = c_int
     lib.dvs_bic_scores.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]
+    lib.dvs_gp_predict.restype = c_int
+    lib.dvs_gp_predict.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, c_void_p, c_void_p]
     lib.dvs_clip_adam.restype = c_int
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_int64, c_float, c_void_p, c_void_p]
@@ -73,7 +76,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores",
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_gp_predict",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
 
 

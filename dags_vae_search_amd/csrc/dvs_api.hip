@@ -737,6 +737,17 @@ extern "C" int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, 
     return dvs_bic_scores_impl(batch, n_vars, n_samples, data, card, parents, scratch, out, status, stream);
 }
 
+extern "C" int dvs_gp_predict_impl(int B, int M, int D, const float* x, const float* z, const double* alpha,
+                                   double outputscale, double lengthscale, double constant, double* out, void* stream);
+extern "C" int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, const float* x, const float* inducing,
+                              const double* alpha, double outputscale, double lengthscale, double constant, double* out,
+                              void* stream) {
+    if (batch <= 0 || n_inducing <= 0 || dim <= 0) return fail(2, "dvs_gp_predict: sizes must be > 0");
+    if (!(lengthscale > 0.0)) return fail(5, "dvs_gp_predict: lengthscale must be > 0");
+    if (!x || !inducing || !alpha || !out) return fail(10, "dvs_gp_predict: null pointer");
+    return dvs_gp_predict_impl(batch, n_inducing, dim, x, inducing, alpha, outputscale, lengthscale, constant, out, stream);
+}
+
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
     if (int e = check_shape(s)) return e;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;

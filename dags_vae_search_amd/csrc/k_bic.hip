@@ -191,3 +191,64 @@ extern "C" int dvs_bic_scores_impl(int B, int n, int S, const uint64_t* data, co
     dvs_launch_bic(a, (dvs_stream_t)stream);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// GP predictor, predictive mean: mean(x*) = c + sum_m o exp(-|x* - z_m|^2 / (2 l^2)) alpha_m for the
+// reference's SGPR model (src/predictors/gp.py:13-32: ConstantMean + InducingPointKernel(ScaleKernel(RBF))), with alpha
+// solved once at fit time.  One wave per query: its 32-dim latent in registers (lane = dimension pair), the M inducing
+// points streamed from global/L2 ([M][32] fp32 = 64 KB), fp64 accumulation: SGPR weights alternate in sign and are
+// orders of magnitude larger than the result.  B x M x 32 MACs — tiny; the kernel exists so that the encode -> predict
+// -> decode loop of latent-space search never leaves the device.
+// ---------------------------------------------------------------------------------------------------------
+struct GpArgs {
+    int B, M, D;
+    const float* x;              // [B][D] queries
+    const float* z;              // [M][D] inducing points
+    const double* alpha;         // [M]
+    double outputscale, inv2l2, constant;
+    double* out;                 // [B]
+};
+__global__ __launch_bounds__(256) void k_gp_predict(GpArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= a.B) return;
+    // lane m-stride: each lane owns inducing points lane, lane + 64, ...; the query is read once per lane (L1 broadcast)
+    double acc = 0.0;
+    for (int m = lane; m < a.M; m += 64) {
+        const float* zm = a.z + (size_t)m * a.D;
+        const float* xq = a.x + (size_t)q * a.D;
+        float d2 = 0.f;
+        for (int k = 0; k < a.D; ++k) {
+            const float d = xq[k] - zm[k];
+            d2 = fmaf(d, d, d2);
+        }
+        acc += a.alpha[m] * exp(-(double)d2 * a.inv2l2);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        // 64-bit shuffle as two 32-bit halves
+        long long bits = __double_as_longlong(acc);
+        int lo = (int)(bits & 0xffffffffLL), hi = (int)(bits >> 32);
+        lo = __shfl_xor(lo, s);
+        hi = __shfl_xor(hi, s);
+        acc += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    if (lane == 0) a.out[q] = a.constant + a.outputscale * acc;
+}
+
+extern "C" int dvs_gp_predict_impl(int B, int M, int D, const float* x, const float* z, const double* alpha,
+                                   double outputscale, double lengthscale, double constant, double* out, void* stream) {
+    GpArgs a;
+    a.B = B;
+    a.M = M;
+    a.D = D;
+    a.x = x;
+    a.z = z;
+    a.alpha = alpha;
+    a.outputscale = outputscale;
+    a.inv2l2 = 0.5 / (lengthscale * lengthscale);
+    a.constant = constant;
+    a.out = out;
+    DVS_LAUNCH(k_gp_predict, dim3((B + 3) / 4), dim3(256), 0, (dvs_stream_t)stream, a);
+    return 0;
+}

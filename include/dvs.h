@@ -92,7 +92,8 @@ int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* pre
 int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
                      const float* eps, float* losses, float* mu, float* logvar, void* stream);
 
-/* Backward of the same step (autograd of pace.py:1974-2035; experiments/03_synthetic_12/main.py:114).
+/* Backward of the same step (autograd of pace.py:1974-2035; experiments/03_synthetic_12/main.py:114).  Must follow
+ * dvs_loss_forward on the same workspace and parameters: it reads the forward's saved activations and per-step weight images.
  * gcoef (device f32[2]): d(objective)/d(recon), d(objective)/d(kld).  grads: flat buffer, overwritten. */
 int dvs_loss_backward(const dvs_shape* s, const void* records, const float* params, void* workspace,
                       const float* gcoef, float* grads, void* stream);
@@ -137,6 +138,16 @@ int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* r
  * otherwise bit 4 of status (device int32, zeroed by the caller) is set and that DAG's score is NaN.  n_vars <= 48. */
 int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, const uint64_t* data, const uint8_t* card,
                    const uint64_t* parents, double* scratch, double* out, int32_t* status, void* stream);
+
+/* Predictive mean of the reference's GP predictor (GPRegressionModel, src/predictors/gp.py:13-32:
+ * ConstantMean + InducingPointKernel(ScaleKernel(RBFKernel())), evaluated as `model(test_x).mean`,
+ * experiments/01_bn_asia/main.py:367-368):  out[b] = constant + outputscale * sum_m alpha[m] exp(-|x_b - z_m|^2 / (2 l^2)).
+ * x: device f32 [batch][dim] (encoder means); inducing: device f32 [n_inducing][dim]; alpha: device f64 [n_inducing]
+ * (solved once at fit time from the training set, see bic/predictor mirror); out: device f64 [batch].  fp64
+ * accumulation.  Parity with gpytorch is unpinned (not installed; no reference predictions exist). */
+int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, const float* x, const float* inducing,
+                   const double* alpha, double outputscale, double lengthscale, double constant, double* out,
+                   void* stream);
 
 /* Optional per-kernel timing for the benchmark's roofline leg: while enabled, every kernel launch is bracketed by
  * HIP events recorded on its own stream; dvs_profile_collect waits for them and returns, per kernel name, the

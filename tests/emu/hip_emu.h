@@ -238,6 +238,7 @@ inline unsigned __float_as_uint(float f) { return emu::bits(f); }
 inline float __uint_as_float(unsigned u) { return emu::from_bits<float>(u); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+inline long long __double_as_longlong(double v) { long long d; memcpy(&d, &v, 8); return d; }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }

@@ -14,6 +14,7 @@ Fixtures written (data only — inputs and expected outputs):
   asia_known_answer.npz   256 rows of experiments/01_bn_asia/data/test/part.0.parquet (labels + edge
                           strings) matched to their ``mu`` vectors in predictor_dataset/part-*.parquet
                           (written by the reference's prepare_predictor_data, main.py:268-303)
+  asia_predictor.npz      the shipped GP predictor's hyper-parameters / inducing points and its 1 408-row data set
   bn_{asia,sachs}_data.npz  the discrete data sets behind the BIC scorer (data/bn_*/target.csv), level-coded u8
   golden_<cfg>.npz        for cfg in {asia, asia_rand (synthetic n=8 graphs, ckpt 110), n12c1, n12c12 and n37c37
                           (alarm-size; fresh-seed parameters, stored under param/; n37c37 is 'slim')}: graphs -> reference outputs: eval-mode
@@ -194,6 +195,7 @@ def main():
     golden(PaceVaeV3, "n12c12", 12, 12, None, ofeat.synthetic_dags(12, 12, 48, seed=12), seed=9)
     golden(PaceVaeV3, "n37c37", 37, 37, None, alarm_graphs(), seed=10, slim=True)
     bn_data()
+    predictor_data()
 
 
 def bn_data():
@@ -210,6 +212,30 @@ def bn_data():
         data = np.stack(cols, 1)
         np.savez_compressed(os.path.join(HERE, f"bn_{name}_data.npz"), data=data, names=np.asarray(names))
         print(f"bn_{name}_data: {data.shape}, levels {(data.max(0) + 1).tolist()}")
+
+
+def predictor_data():
+    """The reference's trained GP predictor as data: hyper-parameters + inducing points of
+    experiments/01_bn_asia/predictor_results/predictor.pth (weights-only load) and the 1 408-row (mu, BIC) data set of
+    experiments/01_bn_asia/predictor_dataset (natural part order, as dask reads it)."""
+    import glob
+    import re
+    sd = torch.load(f"{REF}/experiments/01_bn_asia/predictor_results/predictor.pth", weights_only=True, map_location="cpu")
+    files = sorted(glob.glob(f"{REF}/experiments/01_bn_asia/predictor_dataset/part-*.parquet"),
+                   key=lambda q: int(re.search(r"part-(\d+)", q).group(1)))
+    X, y = [], []
+    for f in files:
+        t = pq.read_table(f).to_pylist()
+        X += [r["vector"] for r in t]
+        y += [r["target"] for r in t]
+    np.savez_compressed(os.path.join(HERE, "asia_predictor.npz"),
+                        x=np.asarray(X, np.float32), y=np.asarray(y, np.float64),
+                        inducing_points=sd["covar_module.inducing_points"].numpy(),
+                        raw_noise=sd["likelihood.noise_covar.raw_noise"].numpy(),
+                        raw_outputscale=sd["base_covar_module.raw_outputscale"].numpy(),
+                        raw_lengthscale=sd["base_covar_module.base_kernel.raw_lengthscale"].numpy(),
+                        raw_constant=sd["mean_module.raw_constant"].numpy())
+    print("asia_predictor:", len(X), "rows")
 
 
 def alarm_graphs():

@@ -87,6 +87,22 @@ struct ReduceArgs {
     int64_t fc_lo1, fc_hi1, fc_lo2, fc_hi2;
 };
 
+// One phase of a chained backward launch (k_bwd_stack, k_backward.hip).  Plain data: the table travels as the kernel argument.
+enum { DVS_PH_FFN = 0, DVS_PH_ATTN = 1, DVS_PH_PROJ1 = 2, DVS_PH_PROJ2 = 3, DVS_PH_PROJ3 = 4 };
+#define DVS_STACK_PHASES 9
+struct BwdPhase {
+    int kind, pad;
+    union {
+        FfnBwdArgs f;
+        AttnBwdArgs a;
+        ProjBwdArgs p;
+    } u;
+};
+struct BwdStackArgs {
+    int nphase, pad;
+    BwdPhase ph[DVS_STACK_PHASES];
+};
+void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 decoder, 1 encoder (profile names)
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st);
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st);
@@ -126,7 +142,7 @@ __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, co
                                              bool cperm = false) {
     constexpr int COLS = 16 * IT, SZ = 256 * OT * IT;
     if (cperm) {                                         // attention slot order -> parameter order (dvs_pi)
-        for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
+        for (int i = dvs_tid(); i < rows * COLS; i += blockDim.x) {
             float s = region[i];
             for (int w = 1; w < L.nwaves; ++w) s += region[w * SZ + i];
             const int row = i / COLS, col = i - row * COLS;
@@ -135,7 +151,7 @@ __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, co
         return;
     }
     if (cols_used == COLS && (ld_dst & 3) == 0) {       // 16-byte path (every 64-wide tensor)
-        for (int i = threadIdx.x * 4; i < rows * COLS; i += blockDim.x * 4) {
+        for (int i = dvs_tid() * 4; i < rows * COLS; i += blockDim.x * 4) {
             f4 s = *(const f4*)(region + i);
             for (int w = 1; w < L.nwaves; ++w) s += *(const f4*)(region + w * SZ + i);
             const int row = i / COLS, col = i - row * COLS;
@@ -143,7 +159,7 @@ __device__ __forceinline__ void dvs_flush_dw(const float* region, float* dst, co
         }
         return;
     }
-    for (int i = threadIdx.x; i < rows * COLS; i += blockDim.x) {
+    for (int i = dvs_tid(); i < rows * COLS; i += blockDim.x) {
         float s = region[i];
         for (int w = 1; w < L.nwaves; ++w) s += region[w * SZ + i];
         const int row = i / COLS, col = i - row * COLS;
@@ -170,7 +186,7 @@ __device__ __forceinline__ void dvs_stage_vec(float* region, const f4 (&v)[NT], 
 template <int NT>
 __device__ __forceinline__ void dvs_flush_vec(const float* region, float* dst, const Lane& L, int n = 16 * NT,
                                               bool perm = false) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = dvs_tid(); i < n; i += blockDim.x) {
         float s = region[i];
         for (int w = 1; w < L.nwaves; ++w) s += region[w * (16 * NT) + i];
         dst[perm ? dvs_pi(i) : i] = s;

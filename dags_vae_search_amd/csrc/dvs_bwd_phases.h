@@ -1,0 +1,607 @@
+// The three phases of the transformer-stack backward — FFN sublayer, stacked-projection (q/k/v) backward with fused
+// LayerNorm backward, attention core — as device functions over one 512-thread workgroup and its dynamic LDS.
+// k_backward.hip wraps each in its own kernel (wide path, per-phase profiling) and chains them in k_bwd_stack: every
+// phase maps DAG `dvs_bid() * 8 + wave (+ gridDim.x * 8 ...)` to the same wave, so the tiles a phase reads were written
+// by the same wave in the phase before and a workgroup barrier is the only synchronisation between phases.
+#pragma once
+#include "dvs_backward.h"
+#include "dvs_wimg.h"
+
+static size_t projb_lds_bytes(int nproj) {
+    return (size_t)2 * nproj * 64 * DVS_LDB * sizeof(dvs_bf16) + (128 + (size_t)8 * 3 * DVS_SCR + 16) * 4;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// FFN sublayer backward (autograd of pace.py:62-65 / 151-153).  Recomputes h = drop(relu(W1 x + b1)) from the saved
+// pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
+// ---------------------------------------------------------------------------------------------------------
+struct FfnBLds {
+    // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as the bf16x6 triple k_ffn_fwd uses: the hidden is
+    // recomputed with the forward's own instruction sequence, because its sign must reproduce the forward's ReLU mask.
+    // The weight GRADIENTS (dvs_coop_dw) stay exact fp32.
+    dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl, *W1x6;
+    float *b1, *b2, *lg, *lb, *og, *ob, *slots;
+};
+__device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
+    FfnBLds l;
+    l.W2Th = (dvs_bf16*)smem;
+    l.W2Tl = l.W2Th + 64 * DVS_LDB;
+    l.W1Th = l.W2Tl + 64 * DVS_LDB;
+    l.W1Tl = l.W1Th + 64 * DVS_LDB;
+    l.W1x6 = l.W1Tl + 64 * DVS_LDB;
+    l.b1 = (float*)(l.W1x6 + 3 * 64 * DVS_LDB);
+    l.b2 = l.b1 + 64;
+    l.lg = l.b2 + 64;
+    l.lb = l.lg + 64;
+    l.og = l.lb + 64;
+    l.ob = l.og + 64;
+    l.slots = l.ob + 64;
+    return l;
+}
+static size_t ffnb_lds_bytes() {
+    return 7 * 64 * DVS_LDB * sizeof(dvs_bf16) + (6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
+}
+
+// 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
+// (dvs_coop_dw): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
+// The two gradient products (d hidden, d x) run on the bf16 matrix pipe as bf16x3: gradient
+// parity is bounded at 2e-3 of the tensor maximum (tests), three orders of magnitude above their ~1e-5 error, whereas
+// the forward keeps exact fp32 MFMAs for the 1e-4 ELBO contract.
+__device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* smem) {
+    const FfnBLds l = ffnb_lds(smem);
+    dvs_copy_image(l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
+    dvs_copy_image(l.W1x6, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(3 * DVS_IMG64));
+    dvs_stage_vector(l.b1, a.l1_b, 64);
+    dvs_stage_vector(l.b2, a.l2_b, 64);
+    if (a.ln.stats) {
+        dvs_stage_vector(l.lg, a.ln.g, 64);
+        dvs_stage_vector(l.lb, a.ln.b, 64);
+    }
+    if (a.own_pre) {
+        dvs_stage_vector(l.og, a.own.g, 64);
+        dvs_stage_vector(l.ob, a.own.b, 64);
+    }
+    int* gcount = (int*)(l.slots + 8 * 2 * DVS_SCR);
+    if (dvs_tid() < 2) gcount[dvs_tid()] = 0;
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int B = a.dims.B * a.dims.NT;                    // tiles (dvs_tile_of): the sublayer is token-local
+    float* sA = l.slots + L.wave * 2 * DVS_SCR;
+    float* sB = sA + DVS_SCR;
+    DvsGroup G = {gcount + (L.wave >> 2), 0};
+    f4 aW1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, aW2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+    float vb1 = 0.f, vb2 = 0.f, vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;    // lane = feature
+    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;                     // tile index
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const DvsTile T = dvs_tile_of((int)dg, a.dims);
+        const int N = T.Nl;
+        const int Nl = live ? N : 0;                       // a wave without a tile carries all-zero tiles
+        f4 x[4], xhat[4], gp[4];
+        float rstd;
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
+        dvs_load_grad(gp, a.gpre, dg, Nl, L);
+        if (a.own_pre) {   // incoming gradient is w.r.t. LN_own(pre_own): pull back to d(pre_own)
+            f4 po[4], pxh[4], t0[4];
+            float prstd;
+            dvs_load_x<true>(po, pxh, prstd, a.own_pre, a.own, l.og, l.ob, dg, Nl, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) t0[t] = gp[t] * pxh[t];
+            dvs_park_T(sA, t0, L);
+            dvs_park_T(sB, gp, L);
+            dvs_wave_sync();
+            vog += dvs_colsum(sA, L);
+            vob += dvs_colsum(sB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(gp, pxh, prstd, l.og, L);
+        }
+        const uint32_t gdag = a.dims.dag_offset + (uint32_t)T.dag;
+        const uint32_t khid = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_hidden, gdag);
+        const uint32_t kpost = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag);
+        // recompute hidden
+        f4 hpre[4], hd[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hpre[t] = dvs_vecT(l.b1, t, L);
+        dvs_matb3<4>(hpre, dvs_split3_T(x), l.W1x6, 64, 0, L);   // the forward's own bf16x6 product, bit for bit: its sign is the ReLU mask
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) hd[t][kk] = (live && L.r < N) ? fmaxf(hpre[t][kk], 0.f) : 0.f;
+        dvs_dropout_tile(hd, khid, D, L, T.tok0);
+        // dy = d(W2 h + b2) = dropout-mask(post) applied to d pre
+        f4 dy[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dy[t] = gp[t];
+        dvs_dropout_tile(dy, kpost, D, L, T.tok0);
+        // ---- dW2 += dy^T hd, db2 += sum dy --------------------------------------------------------------------------
+        dvs_park_T(sA, dy, L);
+        dvs_park_T(sB, hd, L);
+        dvs_wave_sync();
+        vb2 += dvs_colsum(sA, L);
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aW2, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+        dvs_matb_T<4>(dh, dvs_split_T(dy), l.W2Th, l.W2Tl, 0, L);
+        dvs_dropout_tile(dh, khid, D, L, T.tok0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dh[t][kk] = hpre[t][kk] > 0.f ? dh[t][kk] : 0.f;
+        dvs_group_barrier(G, L);
+        // ---- dW1 += dh^T x, db1 += sum dh ----------------------------------------------------------------------------
+        dvs_park_T(sA, dh, L);
+        dvs_park_T(sB, x, L);
+        dvs_wave_sync();
+        vb1 += dvs_colsum(sA, L);
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aW1, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        f4 dx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dx[t] = gp[t];
+        dvs_matb_T<4>(dx, dvs_split_T(dh), l.W1Th, l.W1Tl, 0, L);
+        dvs_group_barrier(G, L);
+        if (a.ln.stats) {
+            f4 t0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) t0[t] = dx[t] * xhat[t];
+            dvs_park_T(sA, t0, L);
+            dvs_park_T(sB, dx, L);
+            dvs_wave_sync();
+            vgam += dvs_colsum(sA, L);
+            vbet += dvs_colsum(sB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(dx, xhat, rstd, l.lg, L);
+        }
+        if (live) dvs_store_tile(a.gout, dag, dx, L);
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)dvs_bid() * a.P;
+    dvs_coop_store((float*)smem, slab + a.o_l1_w, aW1, L);
+    dvs_coop_store((float*)smem, slab + a.o_l2_w, aW2, L);
+    float* red = (float*)smem;                        // [8 waves][6][64]
+    red[(L.wave * 6 + 0) * 64 + L.lane] = vb1;
+    red[(L.wave * 6 + 1) * 64 + L.lane] = vb2;
+    red[(L.wave * 6 + 2) * 64 + L.lane] = vgam;
+    red[(L.wave * 6 + 3) * 64 + L.lane] = vbet;
+    red[(L.wave * 6 + 4) * 64 + L.lane] = vog;
+    red[(L.wave * 6 + 5) * 64 + L.lane] = vob;
+    __syncthreads();
+    if (dvs_tid() < 6 * 64) {
+        const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[(w * 6 + k) * 64 + f];
+        const int64_t off = k == 0 ? a.o_l1_b : k == 1 ? a.o_l2_b : k == 2 ? a.o_ln_g : k == 3 ? a.o_ln_b : k == 4 ? a.o_own_g : a.o_own_b;
+        if (off >= 0) slab[off + f] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward of NPROJ stacked 64->64 projections of one input X (the q/k/v in-projections of nn.MultiheadAttention):
+//   dX^T = sum_p W_p^T dY_p^T (+ residual) ; dW_p += dY_p(N) (x) X(N) ; db_p += sum_tok dY_p ; then the producing
+//   sublayer's LayerNorm backward.  Used for self-attention (NPROJ=3), cross-attention q (1) and k,v (2, X = memory).
+// ---------------------------------------------------------------------------------------------------------
+// 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw):
+// per wave 16 accumulator registers per projection, ~130 VGPRs, two waves per SIMD.  LDS slots per wave: X (kept for
+// all projections of the DAG) and two alternating dY slots, so one group barrier per projection + one per DAG.
+template <int NPROJ>
+__device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* smem) {
+    // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
+    // of the forward depends on it), so it runs on the bf16 matrix pipe; the weight gradients stay exact fp32.
+    dvs_bf16* WT = (dvs_bf16*)smem;                // [NPROJ][hi | lo][64][LDB]
+    float* lg = (float*)(WT + NPROJ * 2 * DVS_IMG64);
+    float* lb = lg + 64;
+    float* slots = lb + 64;                        // per wave 3 tiles: A0, A1 (alternating dY) and B (X)
+    int* gcount = (int*)(slots + 8 * 3 * DVS_SCR);
+    dvs_copy_image(WT, (const dvs_bf16*)a.wimg, (int)(NPROJ * 2 * DVS_IMG64));
+    if (a.ln.stats) {
+        dvs_stage_vector(lg, a.ln.g, 64);
+        dvs_stage_vector(lb, a.ln.b, 64);
+    }
+    if (dvs_tid() < 2) gcount[dvs_tid()] = 0;
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const int B = a.dims.B * a.dims.NT;              // tiles
+    float* myA0 = slots + L.wave * 3 * DVS_SCR;
+    float* myA1 = myA0 + DVS_SCR;
+    float* myB = myA0 + 2 * DVS_SCR;
+    DvsGroup G = {gcount + (L.wave >> 2), 0};
+    f4 aW[NPROJ][4];
+    float vb[NPROJ], vgam = 0.f, vbet = 0.f;
+#pragma unroll
+    for (int p = 0; p < NPROJ; ++p) {
+        vb[p] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
+    }
+    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;               // tile index
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const int Nl = live ? dvs_tile_of((int)dg, a.dims).Nl : 0;
+        f4 x[4], xhat[4], dx[4];
+        float rstd;
+        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dg, Nl, L);
+        if (a.gres) {
+            dvs_load_grad(dx, a.gres, dg, Nl, L);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
+        }
+        dvs_park_T(myB, x, L);
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) {
+            float* mine = (p & 1) ? myA1 : myA0;
+            f4 dy[4];
+            dvs_load_grad(dy, a.gy[p], dg, Nl, L);
+            dvs_park_T(mine, dy, L);
+            dvs_wave_sync();
+            vb[p] += dvs_colsum(mine, L);
+            dvs_group_barrier(G, L);
+            dvs_coop_dw(aW[p], slots + (p & 1) * DVS_SCR, slots + 2 * DVS_SCR, 3 * DVS_SCR, L);
+            dvs_matb_T<4>(dx, dvs_split_T(dy), WT + p * 2 * DVS_IMG64, WT + p * 2 * DVS_IMG64 + DVS_IMG64, 0, L);
+        }
+        dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
+        if (a.ln.stats) {
+            f4 t0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) t0[t] = dx[t] * xhat[t];
+            dvs_park_T(myA0, t0, L);
+            dvs_park_T(myB, dx, L);
+            dvs_wave_sync();
+            vgam += dvs_colsum(myA0, L);
+            vbet += dvs_colsum(myB, L);
+            dvs_wave_sync();
+            dvs_ln_bwd_core(dx, xhat, rstd, lg, L);
+        }
+        if (live) {
+            if (a.accumulate_out) {
+                f4 old[4];
+                dvs_load_tile(old, a.gout, dag, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dx[t] += old[t];
+            }
+            dvs_store_tile(a.gout, dag, dx, L);
+        }
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)dvs_bid() * a.P;
+    const bool so = a.slot_order != 0;
+#pragma unroll
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_store((float*)smem, slab + a.o_w + 4096 * p, aW[p], L, so, false);
+    float* red = (float*)smem;                        // [8 waves][NPROJ + 2][64]
+#pragma unroll
+    for (int p = 0; p < NPROJ; ++p) red[(L.wave * (NPROJ + 2) + p) * 64 + L.lane] = vb[p];
+    red[(L.wave * (NPROJ + 2) + NPROJ) * 64 + L.lane] = vgam;
+    red[(L.wave * (NPROJ + 2) + NPROJ + 1) * 64 + L.lane] = vbet;
+    __syncthreads();
+    if (dvs_tid() < (NPROJ + 2) * 64) {
+        const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[(w * (NPROJ + 2) + k) * 64 + f];
+        if (k < NPROJ) slab[a.o_b + 64 * k + (so ? dvs_pi(f) : f)] = s;
+        else if (a.o_ln_g >= 0) slab[(k == NPROJ ? a.o_ln_g : a.o_ln_b) + f] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention-core backward: from d(pre) of an attention sublayer to d(q), d(k), d(v) projections and dWo/dbo.
+//
+// Recomputes q,k,v and the probabilities of every head (nothing but the sublayer input was saved).  Two
+// orientations of the 16x16 score tile are used so that every product contracts over the MFMA row index of a
+// register-resident operand (see dvs_device.h):
+//   "T":  P^T[j=4g+reg][i=r]  -> softmax statistics (in-lane + 2 shuffles), dP^T, dS^T -> dq^T
+//   "S":  P  [i=4g+reg][j=r]  -> recomputed from the T statistics (3 shuffles), dP, dS -> dk^T, dv^T
+// q,k (T-layout) feed the score products directly; their N-layout copies (for dq/dk), v^T and dO (N) come from
+// per-wave LDS transposes.
+
+struct AttnBLds {
+    float *inb, *outb, *lg, *lb, *slots, *stats;
+    // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
+    // ~1e-5 perturbation stays a ~1e-5 perturbation of the gradient; the FFN's hidden, whose SIGN is a mask, is recomputed
+    // in exact fp32 instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
+    dvs_bf16 *Winh, *Winl, *WoTh, *WoTl;
+    int* gcount;
+};
+__device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
+    AttnBLds l;
+    l.Winh = (dvs_bf16*)smem;
+    l.Winl = l.Winh + 192 * DVS_LDB;
+    l.WoTh = l.Winl + 192 * DVS_LDB;
+    l.WoTl = l.WoTh + 64 * DVS_LDB;
+    l.inb = (float*)(l.WoTl + 64 * DVS_LDB);
+    l.outb = l.inb + 192;
+    l.lg = l.outb + 64;
+    l.lb = l.lg + 64;
+    l.slots = l.lb + 64;                       // per wave: A (d y, row-major) and B (transpose scratch, then O)
+    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
+    l.gcount = (int*)(l.stats + 8 * 128);
+    return l;
+}
+static size_t attnb_lds_floats() {
+    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
+}
+
+// dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
+// reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
+__device__ __forceinline__ f4 mask_T(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return f4_splat(1.f);
+    const uint32_t p0 = (uint32_t)((h * 16 + L.r) * 8 + 2 * L.g);
+    const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+    f4 m;
+    m[0] = ((h0 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[1] = ((h0 >> 16) >= D.thr16) ? D.scale : 0.f;
+    m[2] = ((h1 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[3] = ((h1 >> 16) >= D.thr16) ? D.scale : 0.f;
+    return m;
+}
+__device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+    if (!D.on) return f4_splat(1.f);
+    f4 m;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const uint32_t e = (uint32_t)((h * 16 + 4 * L.g + reg) * 16 + L.r);
+        m[reg] = dvs_dropout_elem(1.0f, key, e, D);
+    }
+    return m;
+}
+
+// 8 waves per workgroup in two independent groups of four (dvs_backward.h); one DAG per wave per iteration.  The
+// out-projection gradient is accumulated cooperatively from the parked d y and O tiles, d q / d k / d v tiles are stored
+// as soon as their head pair is finished, so a wave stays within 256 registers and two waves share each SIMD.
+__device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* smem) {
+    const AttnBLds l = attnb_lds(smem);
+    dvs_copy_image(l.Winh, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, 2 * 192 * DVS_LDB);   // parts hi, mid of the x6 triple = the x3 pair
+    dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));
+    dvs_stage_vector_perm(l.inb, a.in_b, 192);
+    dvs_stage_vector(l.outb, a.out_b, 64);
+    if (a.ln.stats) {
+        dvs_stage_vector(l.lg, a.ln.g, 64);
+        dvs_stage_vector(l.lb, a.ln.b, 64);
+    }
+    if (dvs_tid() < 2) l.gcount[dvs_tid()] = 0;
+    __syncthreads();
+    const Lane L = dvs_lane();
+    const DvsDrop D = dvs_drop_of(a.dims);
+    const int N = a.dims.N, B = a.dims.B;
+    float* sA = l.slots + L.wave * 2 * DVS_SCR;
+    float* sB = sA + DVS_SCR;
+    float* st = l.stats + L.wave * 128;
+    DvsGroup G = {l.gcount + (L.wave >> 2), 0};
+    const float scale = 0.35355339059327373f;
+    f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+    float vbo = 0.f;
+    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+        const int dag = base + L.wave;
+        const bool live = dag < B;
+        const size_t dg = live ? dag : 0;
+        const int Nl = live ? N : 0;
+        const uint32_t gdag = a.dims.dag_offset + (uint32_t)dg;
+        const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
+        const unsigned allowed_r = live ? a.rec[dg].allowed[L.r] : (1u << L.r);
+        f4 q[4], k[4], v[4];
+        {
+            f4 x[4], kv[4], dummy[4];
+            float rstd;
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
+            if (a.kv) {
+                dvs_load_tile(kv, a.kv, dg, L);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kv[t] = x[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                q[t] = dvs_vecT(l.inb, t, L);
+                k[t] = dvs_vecT(l.inb + 64, t, L);
+                v[t] = f4_splat(l.inb[128 + 16 * t + L.r]);
+            }
+            {
+                const SplitT xs = dvs_split_T(x);
+                dvs_matb_T<4>(q, xs, l.Winh, l.Winl, 0, L);
+                if (a.kv) {
+                    const SplitT ks = dvs_split_T(kv);
+                    dvs_matb_T<4>(k, ks, l.Winh, l.Winl, 64, L);
+                    dvs_matb_N<4>(v, ks, l.Winh, l.Winl, 128, L);
+                } else {
+                    dvs_matb_T<4>(k, xs, l.Winh, l.Winl, 64, L);
+                    dvs_matb_N<4>(v, xs, l.Winh, l.Winl, 128, L);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] *= scale;
+        }
+        f4 qN[4], kN[4], vT[4], dOT[4], dON[4];
+        {
+            f4 dy[4];
+            dvs_load_grad(dy, a.gpre, dg, Nl, L);
+            dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
+            dvs_park_T(sA, dy, L);                     // stays parked until the cooperative dWo below
+            dvs_wave_sync();
+            vbo += dvs_colsum(sA, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dOT[t] = f4_zero();
+            dvs_matb_T<4>(dOT, dvs_split_T(dy), l.WoTh, l.WoTl, 0, L);
+        }
+        dvs_t2n<4>(qN, q, sB, L);
+        dvs_t2n<4>(kN, k, sB, L);
+        dvs_n2t<4>(vT, v, sB, L);
+        dvs_t2n<4>(dON, dOT, sB, L);
+
+        const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
+        bool ok[4];
+        unsigned al4[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            ok[reg] = (allowed_r >> (4 * L.g + reg)) & 1u;
+            al4[reg] = (unsigned)__shfl((int)allowed_r, 4 * L.g + reg);
+        }
+        // One feature tile (= one head pair) per pass: the smallest set of live temporaries; the second wave on the SIMD
+        // supplies the instruction-level parallelism that a wider pass would.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) --------------------------------------------
+            f4 pT[2], dsT[2];
+            float lse[2], delta[2];
+            {
+                f4 sT[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    sT[0] = dvs_mfma(k[t][kk], q[t][kk], sT[0]);
+                    sT[1] = dvs_mfma(k[t][kk + 2], q[t][kk + 2], sT[1]);
+                }
+                float m[2], den[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) mx = ok[reg] ? fmaxf(mx, sT[u][reg]) : mx;
+                    m[u] = mx;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 16));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 32));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        pT[u][reg] = ok[reg] ? __expf(sT[u][reg] - m[u]) : 0.f;
+                        sum += pT[u][reg];
+                    }
+                    den[u] = sum;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 32);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    pT[u] *= (1.0f / den[u]);
+                    lse[u] = m[u] + __logf(den[u]);
+                }
+            }
+            {
+                f4 mk[2], dpT[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    mk[u] = mask_T(kprob, 2 * t + u, D, L);
+                    dpT[u] = f4_zero();
+                }
+                // O = P' V (N-layout, columns = slots, per-lane head select), parked row-major in slot B for dWo
+                {
+                    f4 oa = f4_zero(), ob = f4_zero();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        oa = dvs_mfma(pT[0][kk] * mk[0][kk], v[t][kk], oa);
+                        ob = dvs_mfma(pT[1][kk] * mk[1][kk], v[t][kk], ob);
+                    }
+                    float* po = sB + (4 * L.g) * DVS_LD + 16 * t + L.r;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) po[reg * DVS_LD] = hsel ? ob[reg] : oa[reg];
+                }
+                // dP^T = V dO^T
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    dpT[0] = dvs_mfma(vT[t][kk], dOT[t][kk], dpT[0]);
+                    dpT[1] = dvs_mfma(vT[t][kk + 2], dOT[t][kk + 2], dpT[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    dpT[u] *= mk[u];
+                    float dl = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dl += pT[u][reg] * dpT[u][reg];
+                    delta[u] = dl;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 32);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dsT[u][reg] = pT[u][reg] * (dpT[u][reg] - delta[u]);
+            }
+            // dq^T = K^T dS^T: all 16 slot rows per head, merged by register; stored at once (scaled by 1/sqrt(dh))
+            {
+                f4 qa = f4_zero(), qb = f4_zero();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    qa = dvs_mfma(kN[t][kk], dsT[0][kk], qa);
+                    qb = dvs_mfma(kN[t][kk], dsT[1][kk], qb);
+                }
+                const f4 dq = f4{qa[0], qa[1], qb[2], qb[3]} * scale;
+                if (live) ((f4*)(a.gq + dg * DVS_TILE))[t * 64 + L.lane] = dq;
+            }
+            // row statistics (lse, delta) move from lanes r = i to the S-orientation registers i = 4g+reg
+            if (L.g == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    st[u * 32 + L.r] = lse[u];
+                    st[u * 32 + 16 + L.r] = delta[u];
+                }
+            }
+            dvs_wave_sync();
+            // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) --------------------------------------------
+            {
+                f4 s2[2] = {f4_zero(), f4_zero()}, dp[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    s2[0] = dvs_mfma(q[t][kk], k[t][kk], s2[0]);
+                    s2[1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[1]);
+                    dp[0] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[0]);
+                    dp[1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[1]);
+                }
+                f4 ds[2], pd[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f4 lse_i = *(const f4*)(st + u * 32 + 4 * L.g);
+                    const f4 del_i = *(const f4*)(st + u * 32 + 16 + 4 * L.g);
+                    const f4 mk = mask_S(kprob, 2 * t + u, D, L);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const bool oki = (al4[reg] >> L.r) & 1u;
+                        const float p = oki ? __expf(s2[u][reg] - lse_i[reg]) : 0.f;
+                        ds[u][reg] = p * (dp[u][reg] * mk[reg] - del_i[reg]);
+                        pd[u][reg] = p * mk[reg];
+                    }
+                }
+                dvs_wave_sync();
+                // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register), stored at once
+                f4 ka = f4_zero(), kb = f4_zero(), va = f4_zero(), vb = f4_zero();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    ka = dvs_mfma(qN[t][kk], ds[0][kk], ka);
+                    kb = dvs_mfma(qN[t][kk], ds[1][kk], kb);
+                    va = dvs_mfma(dON[t][kk], pd[0][kk], va);
+                    vb = dvs_mfma(dON[t][kk], pd[1][kk], vb);
+                }
+                if (live) {
+                    ((f4*)(a.gk + dg * DVS_TILE))[t * 64 + L.lane] = f4{ka[0], ka[1], kb[2], kb[3]};
+                    ((f4*)(a.gv + dg * DVS_TILE))[t * 64 + L.lane] = f4{va[0], va[1], vb[2], vb[3]};
+                }
+            }
+            DVS_SCHED_FENCE();
+        }
+        // ---- dWo += dy^T O over the group's DAGs ------------------------------------------------------------------
+        dvs_group_barrier(G, L);
+        dvs_coop_dw(aWo, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        dvs_group_barrier(G, L);
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)dvs_bid() * a.P;
+    dvs_coop_store((float*)smem, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
+    float* red = (float*)smem;
+    red[L.wave * 64 + L.lane] = vbo;
+    __syncthreads();
+    if (dvs_tid() < 64) {
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += red[w * 64 + dvs_tid()];
+        slab[a.o_out_b + dvs_tid()] = s;
+    }
+}
+

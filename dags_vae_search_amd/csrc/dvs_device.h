@@ -47,16 +47,36 @@ struct DvsRecord {               // compact per-DAG record written by dvs_pack_f
     uint16_t allowed[16];        // bit j: token i may attend token j (target_masks[., i, j] == False)
 };
 
+// Work-item / workgroup index behind an optimisation barrier: inside k_bwd_stack's phase loop the compiler otherwise hoists
+// every phase's lane-derived LDS addresses out of the loop and spills them (158 VGPR spills); an opaque id keeps each phase's
+// address arithmetic inside the phase.
+#ifndef DVS_EMU
+__device__ __forceinline__ int dvs_tid() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+__device__ __forceinline__ int dvs_bid() {
+    int b = (int)blockIdx.x;
+    asm volatile("" : "+s"(b));
+    return b;
+}
+#else
+__device__ __forceinline__ int dvs_tid() { return (int)threadIdx.x; }
+__device__ __forceinline__ int dvs_bid() { return (int)blockIdx.x; }
+#endif
+
 struct Lane {
     int lane, r, g, wave, nwaves;
 };
 
 __device__ __forceinline__ Lane dvs_lane() {
     Lane L;
-    L.lane = threadIdx.x & 63;
+    const int t = dvs_tid();
+    L.lane = t & 63;
     L.r = L.lane & 15;
     L.g = L.lane >> 4;
-    L.wave = threadIdx.x >> 6;
+    L.wave = t >> 6;
     L.nwaves = blockDim.x >> 6;
     return L;
 }
@@ -96,8 +116,8 @@ __device__ __forceinline__ void dvs_stage_matrix(float* dst, int ldl, const floa
     // and every workgroup starts at a different element: all workgroups of a launch read the same matrix at the same time
     // and would otherwise queue on the same L2 lines (measured on the bf16 images: +5 % DAGs/s).
     const int c4 = cols >> 2, n = rows * c4, step = blockDim.x;
-    const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n);
-    int i = threadIdx.x;
+    const int rot = (int)(((unsigned)dvs_bid() * 2654435761u) % (unsigned)n);
+    int i = dvs_tid();
     for (; i + 3 * step < n; i += 4 * step) {
         f4 v[4];
         int off[4];
@@ -120,7 +140,7 @@ __device__ __forceinline__ void dvs_stage_matrix(float* dst, int ldl, const floa
     }
 }
 __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    for (int i = dvs_tid(); i < n; i += blockDim.x) dst[i] = src[i];
 }
 
 // ---- head-aligned slot order inside the attention sublayers -------------------------------------------------------
@@ -133,7 +153,7 @@ __device__ __forceinline__ void dvs_stage_vector(float* dst, const float* __rest
 // 4 half-masked ones, and the per-head outputs are merged by register selection.  pi is an involution.
 __device__ __forceinline__ int dvs_pi(int i) { return (i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3); }
 __device__ __forceinline__ void dvs_stage_vector_perm(float* dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[dvs_pi(i)];
+    for (int i = dvs_tid(); i < n; i += blockDim.x) dst[i] = src[dvs_pi(i)];
 }
 
 // row fragment: element kk = W[row0 + r][16t + 4g + kk]

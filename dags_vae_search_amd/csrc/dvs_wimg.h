@@ -56,8 +56,8 @@ __device__ __forceinline__ void dvs_copy_image(dvs_bf16* dst, const dvs_bf16* __
     const int n16 = n >> 3, step = blockDim.x;
     // every workgroup of the launch copies the SAME image at the same time: start each one at a different offset so that
     // they do not all queue on the same L2 lines
-    const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n16);
-    int i = threadIdx.x;
+    const int rot = (int)(((unsigned)dvs_bid() * 2654435761u) % (unsigned)n16);
+    int i = dvs_tid();
     for (; i + 7 * step < n16; i += 8 * step) {
         f4 v[8];
         int j[8];

@@ -168,6 +168,8 @@ class PaceVaeV3(nn.Module):
         self.flat_grads: Optional[torch.Tensor] = None
         self._fwd_generation = 0
         self._last_losses = None
+        self._side_stream = None       # early loss read-back of the fused train step (_early_read)
+        self._early_pending = False
         self._seed = 0
         self._step = 0
         self.dag_offset = 0            # global index of the first DAG of the next batch (data-parallel shards)
@@ -235,6 +237,8 @@ class PaceVaeV3(nn.Module):
         out = super()._apply(fn, recurse)
         self._flatten()
         self._engine = None
+        self._side_stream = None
+        self._early_pending = False
         return out
 
     def bind_flat_grads(self) -> torch.Tensor:
@@ -307,13 +311,36 @@ class PaceVaeV3(nn.Module):
         eng.pack(f, check=check, zero_status=zero_status)
         return f["vertex_label_features"].shape[0]
 
+    def _early_read(self):
+        """Called between the forward and the backward of a fused step: the [losses, validation word] tail is final once
+        the forward has run, so its device->host copy (and the re-arming of the validation word) goes to a side stream
+        behind an event.  The host then blocks only until the FORWARD is done — where the reference's ``loss.item()``
+        blocks (main.py:104) — and enqueues the next step while this step's backward and optimiser are still running."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.flat_params.device)
+            self._ev_forward = torch.cuda.Event()
+            self._ev_tail = torch.cuda.Event()
+        self._ev_forward.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side_stream):
+            self._side_stream.wait_event(self._ev_forward)
+            self._host_tail.copy_(self._step_tail, non_blocking=True)
+            self._step_status.zero_()
+            self._ev_tail.record(self._side_stream)
+        self._early_pending = True
+
     def read_step(self):
-        """End of a fused train step: ONE pinned device->host copy of [total, recon, kld, non-finite flag, validation
-        bits] and one stream synchronisation; the validation word is re-armed behind the copy, so the next step's first
-        GPU work is its pack kernel.  Returns (losses list of 4 floats, status int)."""
-        self._host_tail.copy_(self._step_tail, non_blocking=True)
-        self._step_status.zero_()
-        torch.cuda.current_stream().synchronize()
+        """The one host synchronisation of a fused train step: a pinned device->host copy of [total, recon, kld,
+        non-finite flag, validation bits]; the validation word is re-armed behind the copy.  After ``_early_read`` the
+        copy is already in flight on the side stream (wait for its event); otherwise it is issued here, at the end of the
+        step (data-parallel steps: the loss scalars are only global after the all-reduce).
+        Returns (losses list of 4 floats, status int)."""
+        if self._early_pending:
+            self._early_pending = False
+            self._ev_tail.synchronize()
+        else:
+            self._host_tail.copy_(self._step_tail, non_blocking=True)
+            self._step_status.zero_()
+            torch.cuda.current_stream().synchronize()
         vals = self._host_tail.tolist()
         status = int(self._host_tail.view(torch.int32)[4])
         return vals[:4], status
@@ -412,7 +439,7 @@ class PaceVaeV3(nn.Module):
 
     # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
-                      packed: bool = False, defer_check: bool = False) -> torch.Tensor:
+                      packed: bool = False, defer_check: bool = False, early_read: bool = False) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag]; nothing is synchronised."""
         eng = self._eng()
@@ -427,6 +454,8 @@ class PaceVaeV3(nn.Module):
         losses = self._step_losses            # tail of the gradient allocation (see bind_flat_grads); rewritten each step
         eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
+        if early_read:
+            self._early_read()
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta

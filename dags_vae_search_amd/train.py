@@ -46,12 +46,14 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
     if isinstance(optimizer, FusedAdam):
         if optimizer._model is None:
             optimizer.attach(model)
-        losses = model.loss_and_grad(batch, defer_check=True)     # feature validation is read with the losses below
+        # feature validation is read with the losses below; single-GPU: the read-back starts right after the forward
+        losses = model.loss_and_grad(batch, defer_check=True, early_read=group is None)
         if group is not None:
             from .dist import allreduce_gradients
             allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
         optimizer.step(max_grad_norm=max_grad_norm)
-        recon, kld = losses[1].clone(), losses[2].clone()          # `losses` is a reused device buffer
+        scalars = losses.clone()                                    # `losses` is a reused device buffer
+        recon, kld = scalars[1], scalars[2]
         host, status = model.read_step()                            # the step's only host sync (one 32-byte copy)
         if status != 0:
             raise ValueError(f"batch violates the feature invariants (status bits {status:#x})")

@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "dags_vae_search_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 CXX = os.environ.get("DVS_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-SOURCES = ["k_forward.hip", "k_heads.hip", "k_backward.hip", "k_backward_attn.hip", "k_backward_heads.hip", "k_optim.hip", "k_wide_fwd.hip", "k_wide_bwd.hip", "k_decode.hip", "k_bic.hip", "dvs_api.hip"]
+SOURCES = ["k_forward.hip", "k_heads.hip", "k_backward.hip", "k_backward_heads.hip", "k_optim.hip", "k_wide_fwd.hip", "k_wide_bwd.hip", "k_decode.hip", "k_bic.hip", "dvs_api.hip"]
 
 
 def build(force=False, opt="-O2"):

@@ -423,6 +423,38 @@ static void launch_attn_fwd(const AttnArgs& a, const FwdGrids& g, dvs_stream_t s
     if (g.wide) dvs_launch_attn_fwd_w(a, g.dags, st);
     else dvs_launch_attn_fwd(a, g.attn, st);
 }
+// One-tile path: the sublayers of the encoder / decoder are chained into one launch each (k_fwd_stack); the wide path and
+// DVS_SPLIT_STACK=1 (per-phase profiling) launch every sublayer on its own.
+struct FwdChain {
+    FwdStackArgs stack;
+    const FwdGrids& g;
+    dvs_stream_t st;
+    int tag;
+    bool chain;
+    FwdChain(const FwdGrids& grids, int tag_, dvs_stream_t st_) : g(grids), st(st_), tag(tag_) {
+        static const bool split_env = getenv("DVS_SPLIT_STACK") && atoi(getenv("DVS_SPLIT_STACK")) != 0;
+        memset(&stack, 0, sizeof(stack));
+        chain = !g.wide && !split_env;
+    }
+    FwdPhase& next(int kind) {
+        if (stack.nphase == DVS_FWD_STACK_PHASES) flush();
+        FwdPhase& ph = stack.ph[stack.nphase++];
+        ph.kind = kind;
+        return ph;
+    }
+    void attn(const AttnArgs& a) {
+        if (chain) next(DVS_FPH_ATTN).u.a = a;
+        else launch_attn_fwd(a, g, st);
+    }
+    void ffn(const FfnArgs& f) {
+        if (chain) next(DVS_FPH_FFN).u.f = f;
+        else dvs_launch_ffn_fwd(f, g.tiles16, st);
+    }
+    void flush() {
+        if (stack.nphase > 0) dvs_launch_fwd_stack(stack, tag, g.tiles8, st);
+        stack.nphase = 0;
+    }
+};
 
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
                             const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st) {
@@ -437,6 +469,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
     e.out = ws + W.act[0];
     e.site = 0;
     launch_embed_fwd(e, grid, st);
+    FwdChain chain(grid, 0, st);
     DvsLN ln = {nullptr, nullptr, nullptr};
     int prev = 0;
     for (int i = 0; i < DVS_LAYERS; ++i) {
@@ -457,7 +490,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.out_stats = ws + W.stats[sa];
         a.site_prob = site_enc(i, 0);
         a.site_post = site_enc(i, 1);
-        launch_attn_fwd(a, grid, st);
+        chain.attn(a);
         FfnArgs f;
         memset(&f, 0, sizeof(f));
         f.dims = d;
@@ -478,10 +511,11 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
             f.ng = P + L.enc[i].n2.w;
             f.nb = P + L.enc[i].n2.b;
         }
-        dvs_launch_ffn_fwd(f, grid.tiles16, st);
+        chain.ffn(f);
         ln = DvsLN{ws + W.stats[sf], P + L.enc[i].n2.w, P + L.enc[i].n2.b};
         prev = sf;
     }
+    chain.flush();
 }
 
 static LatentArgs latent_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const float* P, float* ws,
@@ -530,6 +564,7 @@ LossArgs dvs_loss_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace&
 // TransformerDecoder forward (pace.py:163-182) from the embedding in slot `dec_in`; memory = W.mem.
 static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
                             const float* params, float* ws, const FwdGrids& grid, int dec_in, dvs_stream_t st) {
+    FwdChain chain(grid, 1, st);
     DvsLN ln = {nullptr, nullptr, nullptr};
     int prev = dec_in;
     for (int i = 0; i < DVS_LAYERS; ++i) {
@@ -550,7 +585,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.out_stats = ws + W.stats[s0];
         a.site_prob = site_dec(i, 0);
         a.site_post = site_dec(i, 1);
-        launch_attn_fwd(a, grid, st);
+        chain.attn(a);
 
         AttnArgs c;
         memset(&c, 0, sizeof(c));
@@ -569,7 +604,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         c.out_stats = ws + W.stats[s1];
         c.site_prob = site_dec(i, 2);
         c.site_post = site_dec(i, 3);
-        launch_attn_fwd(c, grid, st);
+        chain.attn(c);
 
         FfnArgs f;
         memset(&f, 0, sizeof(f));
@@ -586,10 +621,11 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         f.out_stats = ws + W.stats[s2];
         f.site_hidden = site_dec(i, 4);
         f.site_post = site_dec(i, 5);
-        dvs_launch_ffn_fwd(f, grid.tiles16, st);
+        chain.ffn(f);
         ln = DvsLN{ws + W.stats[s2], params + pl.n3.w, params + pl.n3.b};
         prev = s2;
     }
+    chain.flush();
 }
 
 extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,

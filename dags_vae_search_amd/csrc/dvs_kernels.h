@@ -106,6 +106,21 @@ struct BuildArgs {
 void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st);
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st);
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st);
+// One phase of a chained forward launch (k_fwd_stack, k_forward.hip): attention or FFN sublayer of the one-tile path.
+enum { DVS_FPH_ATTN = 0, DVS_FPH_FFN = 1 };
+#define DVS_FWD_STACK_PHASES 9
+struct FwdPhase {
+    int kind, pad;
+    union {
+        AttnArgs a;
+        FfnArgs f;
+    } u;
+};
+struct FwdStackArgs {
+    int nphase, pad;
+    FwdPhase ph[DVS_FWD_STACK_PHASES];
+};
+void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 encoder, 1 decoder (profile names)
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st);
 int dvs_attn_fwd_waves();
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st);

@@ -374,15 +374,14 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
 #ifndef DVS_ATTN_FWD_THREADS
 #define DVS_ATTN_FWD_THREADS 512
 #endif
-__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
-    DVS_DYN_LDS(smem);
+__device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem) {
     const AttnLds l = attn_lds(smem);
     attn_stage(l, a.wimg, a.in_b, a.out_b, a.ln);
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    for (int dag = dvs_bid() * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
         f4 x[4], dummy[4];
         float rstd;
         dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
@@ -436,6 +435,11 @@ __global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
     }
 }
 
+__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
+    DVS_DYN_LDS(smem);
+    dvs_attn_fwd_phase(a, smem);
+}
+
 int dvs_attn_fwd_waves() { return DVS_ATTN_FWD_THREADS / 64; }
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attn_lds_bytes();
@@ -464,9 +468,7 @@ __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
 }
 static size_t ffn_lds_bytes() { return 6 * 64 * DVS_LDB * sizeof(dvs_bf16) + 6 * 64 * sizeof(float); }
 
-// 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.
-__global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
-    DVS_DYN_LDS(smem);
+__device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem) {
     const FfnLds l = ffn_lds(smem);
     dvs_copy_image(l.W1, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(6 * DVS_IMG64));     // W1, W2 bf16x6 images
     dvs_stage_vector(l.b1, a.l1_b, 64);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int ntiles = a.dims.B * a.dims.NT;
-    for (int tile = blockIdx.x * L.nwaves + L.wave; tile < ntiles; tile += gridDim.x * L.nwaves) {
+    for (int tile = dvs_bid() * L.nwaves + L.wave; tile < ntiles; tile += gridDim.x * L.nwaves) {
         const DvsTile T = dvs_tile_of(tile, a.dims);
         f4 x[4], dummy[4];
         float rstd;
@@ -528,10 +530,44 @@ __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
     }
 }
 
+// 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.
+__global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
+    DVS_DYN_LDS(smem);
+    dvs_ffn_fwd_phase(a, smem);
+}
+
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffn_lds_bytes();
     DVS_SET_LDS(k_ffn_fwd, lds);
     DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Up to DVS_FWD_STACK_PHASES consecutive sublayers of the encoder / decoder in ONE launch (one-tile path), 8 waves per
+// workgroup.  Both phase kinds map tile `blockIdx.x * 8 + wave (+ gridDim.x * 8 ...)` to the same wave, so a phase reads
+// tiles and LayerNorm statistics its own workgroup wrote; a workgroup barrier is the only synchronisation (k_bwd_stack).
+// ---------------------------------------------------------------------------------------------------------
+template <int TAG>
+__global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
+    DVS_DYN_LDS(smem);
+    for (int i = 0; i < s.nphase; ++i) {
+        const FwdPhase& ph = s.ph[i];
+        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem);
+        else dvs_ffn_fwd_phase(ph.u.f, smem);
+        __syncthreads();
+    }
+}
+
+void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, dvs_stream_t st) {
+    const size_t la = attn_lds_bytes(), lf = ffn_lds_bytes();
+    const size_t lds = la > lf ? la : lf;
+    if (tag == 0) {
+        DVS_SET_LDS(k_fwd_stack<0>, lds);
+        DVS_LAUNCH(k_fwd_stack<0>, dim3(grid), dim3(512), lds, st, s);
+    } else {
+        DVS_SET_LDS(k_fwd_stack<1>, lds);
+        DVS_LAUNCH(k_fwd_stack<1>, dim3(grid), dim3(512), lds, st, s);
+    }
 }
 
 // frag-order [tiles][1024] -> natural [tiles][16][64] (= [B][16*NT][64]) (debug / tests)

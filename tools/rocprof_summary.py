@@ -3,6 +3,7 @@
 profiles/.  Usage:
     tools/rocprof_summary.py stats  <trace_results.db>                  > profiles/rNN_kernel_stats.csv
     tools/rocprof_summary.py gaps   <trace_results.db>                  (GPU busy / idle per train step)
+    tools/rocprof_summary.py timeline <trace_results.db> [step]         (one step: start offset, duration, gap before)
     tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   > profiles/rNN_pmc.csv  (per-dispatch averages;
                                                                         from rocprofv3 --pmc ... --output-format csv)
 Counter passes are collected separately (rocprofv3 --kernel-trace --pmc A B ...; gpurun refuses --pmc with --stats)."""
@@ -28,6 +29,19 @@ def stats(db):
     print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"')
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print(f'"{k}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{100.0 * sum(v) / total:.2f},{min(v)},{max(v)}')
+
+
+def timeline(db, step=8):
+    rows = kernels(db)
+    names = [short(r[0]) for r in rows]
+    idx = [i for i, n in enumerate(names) if n in ("k_pack", "k_pack_w")]
+    a, b = idx[step], idx[step + 1]
+    t0 = rows[a][1]
+    prev_end = rows[a - 1][2] if a > 0 else t0
+    print("kernel,start_us,duration_us,gap_before_us")
+    for name, s, e in rows[a:b + 1]:
+        print(f"{short(name)[:60]},{(s - t0) / 1e3:.1f},{(e - s) / 1e3:.1f},{(s - prev_end) / 1e3:.1f}")
+        prev_end = max(prev_end, e)
 
 
 def gaps(db):
@@ -71,6 +85,8 @@ if __name__ == "__main__":
         stats(sys.argv[2])
     elif mode == "gaps":
         gaps(sys.argv[2])
+    elif mode == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 8)
     elif mode == "pmc-csv":
         pmc_csv(sys.argv[2:])
     else:

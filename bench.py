@@ -50,7 +50,7 @@ def algo_flops_per_dag(N: int, C: int):
     edge = 2 * proj + pairs * 64 * 3
     emb = 2.0 * N * 64 * 32 + N * 64 * 3
     latent_f = 2.0 * N * 64 * 64 + 2.0 * 32 * N * 64
-    return {
+    f = {
         "k_embed_fwd": emb, "k_attn_fwd": 4 * proj + core, "k_ffn_fwd": 2 * proj, "k_latent_fwd": latent_f,
         "k_loss_fwd": node + edge,
         # backward kernels: recompute (1x forward) + gradients (2x forward) of the ops they own
@@ -59,6 +59,23 @@ def algo_flops_per_dag(N: int, C: int):
         "k_proj_bwd<3>": 2 * 3 * proj, "k_proj_bwd<2>": 2 * 2 * proj, "k_proj_bwd<1>": 2 * proj,
         "k_latent_bwd": 2.0 * 32 * N * 64 + 2.0 * N * 64 * 64, "k_fc_dw": latent_f, "k_embed_bwd": 2 * emb,
     }
+    # chained launches (one-tile path): the sum over the sublayers one launch walks.  The decoder's 18 backward phases
+    # go out as two launches of 9, so its per-launch figure is half the decoder total.
+    f["k_fwd_stack<0>"] = 3 * (f["k_attn_fwd"] + f["k_ffn_fwd"])
+    f["k_fwd_stack<1>"] = 3 * (2 * f["k_attn_fwd"] + f["k_ffn_fwd"])
+    f["k_bwd_stack<0>"] = 3 * (f["k_ffn_bwd"] + 2 * f["k_attn_bwd"] + f["k_proj_bwd<1>"] + f["k_proj_bwd<2>"]
+                               + f["k_proj_bwd<3>"]) / 2
+    f["k_bwd_stack<1>"] = 3 * (f["k_ffn_bwd"] + f["k_attn_bwd"] + f["k_proj_bwd<3>"])
+    return f
+
+
+STACK_PHASES = {   # what one launch of a chained kernel walks (csrc/k_forward.hip, k_backward.hip)
+    "k_fwd_stack<0>": "encoder forward: 3 x (attention, FFN)",
+    "k_fwd_stack<1>": "decoder forward: 3 x (self-attention, cross-attention, FFN)",
+    "k_bwd_stack<0>": "decoder backward, 9 of its 18 phases per launch: 3 x (FFN, cross-attention core, q projection, "
+                      "k/v projections, self-attention core, q/k/v projections)",
+    "k_bwd_stack<1>": "encoder backward: 3 x (FFN, attention core, q/k/v projections)",
+}
 
 
 def bytes_per_dag(N: int, C: int, P: int, B_local: int) -> float:
@@ -234,6 +251,7 @@ def main():
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(dom, args.batch),
                     "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
                     "algorithmic_flops_per_dag": flops.get(dom_key, 0.0),
+                    **({"phases": STACK_PHASES[dom_key]} if dom_key in STACK_PHASES else {}),
                     "whole_step": {"tflops": value / world * step_flops / 1e12,
                                    "frac_f32_mfma_peak": value / world * step_flops / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                    "hbm_algorithmic_GBs": value / world * bytes_per_dag(N, C, P, args.batch) / 1e9,

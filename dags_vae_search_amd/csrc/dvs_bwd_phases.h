@@ -324,28 +324,57 @@ static size_t attnb_lds_floats() {
     return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
 }
 
-// dropout multipliers (0 or 1/keep) of head h; T orientation: reg <-> (i = r, j = 4g+reg); S orientation:
-// reg <-> (i = 4g+reg, j = r); element index ((h*16 + i)*16 + j) in both.
-__device__ __forceinline__ f4 mask_T(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
-    if (!D.on) return f4_splat(1.f);
-    const uint32_t p0 = (uint32_t)((h * 16 + L.r) * 8 + 2 * L.g);
-    const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
-    f4 m;
-    m[0] = ((h0 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
-    m[1] = ((h0 >> 16) >= D.thr16) ? D.scale : 0.f;
-    m[2] = ((h1 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
-    m[3] = ((h1 >> 16) >= D.thr16) ? D.scale : 0.f;
+// Dropout keep-bits of the attention probabilities of one DAG, all 8 heads.  T orientation: lane (r, g) owns the elements
+// (query i = r, key j = 4g + reg) -> bit 4h + reg of `T`, drawn exactly like the forward does (element index
+// (h*16 + i)*16 + j, two elements per draw).  S orientation: lane (r, g) owns (i = 4g + reg, j = r), i.e. the bits that
+// lane (r' = 4g + reg, g' = r >> 2) holds at reg' = r & 3: four cross-lane reads instead of 32 more hash draws.
+// v if bit `pos` of `bits` is set, else +0: a signed 1-bit field extract (0 / -1) ANDed onto the value
+__device__ __forceinline__ float dvs_bit_select(uint32_t bits, int pos, float v) {
+#ifndef DVS_EMU
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);      // v_bfe_i32: 0 or -1
+#else
+    const uint32_t m = ((bits >> pos) & 1u) ? 0xFFFFFFFFu : 0u;
+#endif
+    return __uint_as_float(__float_as_uint(v) & m);
+}
+struct ProbMask {
+    uint32_t T;
+    uint32_t S[4];      // S[reg] >> (4h) & 1: element (i = 4g + reg, j = r) of head h
+};
+__device__ __forceinline__ ProbMask dvs_prob_mask(uint32_t key, const DvsDrop& D, const Lane& L) {
+    ProbMask m;
+    m.T = 0xFFFFFFFFu;
+    if (D.on) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const uint32_t p0 = (uint32_t)((h * 16 + L.r) * 8 + 2 * L.g);
+            const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+            bits |= ((h0 & 0xFFFFu) >= D.thr16 ? 1u : 0u) << (4 * h);
+            bits |= ((h0 >> 16) >= D.thr16 ? 1u : 0u) << (4 * h + 1);
+            bits |= ((h1 & 0xFFFFu) >= D.thr16 ? 1u : 0u) << (4 * h + 2);
+            bits |= ((h1 >> 16) >= D.thr16 ? 1u : 0u) << (4 * h + 3);
+        }
+        m.T = bits;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+        m.S[reg] = D.on ? ((uint32_t)__shfl((int)m.T, 4 * L.g + reg + 16 * (L.r >> 2)) >> (L.r & 3)) : 0xFFFFFFFFu;
     return m;
 }
-__device__ __forceinline__ f4 mask_S(uint32_t key, int h, const DvsDrop& D, const Lane& L) {
+__device__ __forceinline__ f4 mask_T(const ProbMask& m, int h, const DvsDrop& D) {
     if (!D.on) return f4_splat(1.f);
-    f4 m;
+    f4 r;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const uint32_t e = (uint32_t)((h * 16 + 4 * L.g + reg) * 16 + L.r);
-        m[reg] = dvs_dropout_elem(1.0f, key, e, D);
-    }
-    return m;
+    for (int reg = 0; reg < 4; ++reg) r[reg] = dvs_bit_select(m.T, 4 * h + reg, D.scale);
+    return r;
+}
+__device__ __forceinline__ f4 mask_S(const ProbMask& m, int h, const DvsDrop& D) {
+    if (!D.on) return f4_splat(1.f);
+    f4 r;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) r[reg] = dvs_bit_select(m.S[reg], 4 * h, D.scale);
+    return r;
 }
 
 // 8 waves per workgroup in two independent groups of four (dvs_backward.h); one DAG per wave per iteration.  The
@@ -430,6 +459,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         dvs_n2t<4>(vT, v, sB, L);
         dvs_t2n<4>(dON, dOT, sB, L);
 
+        const ProbMask pm = dvs_prob_mask(kprob, D, L);
         const bool hsel = ((L.r & 3) >> 1) != 0;     // N-layout lane r holds slot r = feature 4(r&3) + (r>>2): head bit
         bool ok[4];
         unsigned al4[4];
@@ -488,7 +518,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                 f4 mk[2], dpT[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    mk[u] = mask_T(kprob, 2 * t + u, D, L);
+                    mk[u] = mask_T(pm, 2 * t + u, D);
                     dpT[u] = f4_zero();
                 }
                 // O = P' V (N-layout, columns = slots, per-lane head select), parked row-major in slot B for dWo
@@ -561,7 +591,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                 for (int u = 0; u < 2; ++u) {
                     const f4 lse_i = *(const f4*)(st + u * 32 + 4 * L.g);
                     const f4 del_i = *(const f4*)(st + u * 32 + 16 + 4 * L.g);
-                    const f4 mk = mask_S(kprob, 2 * t + u, D, L);
+                    const f4 mk = mask_S(pm, 2 * t + u, D);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const bool oki = (al4[reg] >> L.r) & 1u;

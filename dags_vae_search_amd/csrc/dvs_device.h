@@ -57,7 +57,7 @@ __device__ __forceinline__ int dvs_tid() {
     return t;
 }
 __device__ __forceinline__ int dvs_bid() {
-    int b = (int)blockIdx.x;
+    int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);   // pins the value to a scalar register whatever the caller did with it
     asm volatile("" : "+s"(b));
     return b;
 }

@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256) void k_sqnorm_part(const float* g, int64_t n, 
     }
     if (threadIdx.x == 0) scratch[2 + blockIdx.x] = part[0];
 }
-__global__ __launch_bounds__(256) void k_sqnorm_final(float max_norm, float* scratch) {
+// Every workgroup of k_adam re-derives the clip coefficient from the 256 partials (same tree, same order: bitwise the same
+// value everywhere) instead of waiting for a one-workgroup launch in between; workgroup 0 publishes it.
+__global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
+                                              float eps, float bc1, float bc2_sqrt, float max_norm, float* scratch) {
     __shared__ float part[256];
     part[threadIdx.x] = scratch[2 + threadIdx.x];
     __syncthreads();
@@ -31,23 +34,18 @@ __global__ __launch_bounds__(256) void k_sqnorm_final(float max_norm, float* scr
         if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const float ss = part[0];
+    const float ss = part[0];
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+        coef = max_norm / (sqrtf(ss) + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         scratch[0] = ss;
-        float coef = 1.0f;
-        if (max_norm > 0.f) {
-            coef = max_norm / (sqrtf(ss) + 1e-6f);
-            coef = coef < 1.0f ? coef : 1.0f;
-        }
         scratch[1] = coef;
     }
-}
-
-__global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt, const float* scratch) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float coef = scratch[1];
     const float gi = g[i] * coef;
     g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -61,11 +59,10 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
                           float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st) {
     DVS_LAUNCH(k_sqnorm_part, dim3(SQ_PARTS), dim3(256), 0, st, (const float*)grads, n, scratch);
-    DVS_LAUNCH(k_sqnorm_final, dim3(1), dim3(256), 0, st, max_norm, scratch);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
     DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
-                       bc1, sqrtf(bc2), (const float*)scratch);
+                       bc1, sqrtf(bc2), max_norm, scratch);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -170,6 +170,7 @@ class PaceVaeV3(nn.Module):
         self._last_losses = None
         self._side_stream = None       # early loss read-back of the fused train step (_early_read)
         self._early_pending = False
+        self._early_scalars = None
         self._seed = 0
         self._step = 0
         self.dag_offset = 0            # global index of the first DAG of the next batch (data-parallel shards)
@@ -325,6 +326,7 @@ class PaceVaeV3(nn.Module):
             self._side_stream.wait_event(self._ev_forward)
             self._host_tail.copy_(self._step_tail, non_blocking=True)
             self._step_status.zero_()
+            self._early_scalars = self._step_losses.clone()     # the caller's recon / kld tensors (ready once _ev_tail is)
             self._ev_tail.record(self._side_stream)
         self._early_pending = True
 

@@ -52,9 +52,12 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
             from .dist import allreduce_gradients
             allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
         optimizer.step(max_grad_norm=max_grad_norm)
-        scalars = losses.clone()                                    # `losses` is a reused device buffer
-        recon, kld = scalars[1], scalars[2]
+        early = group is None
+        scalars = None if early else losses.clone()                 # `losses` is a reused device buffer
         host, status = model.read_step()                            # the step's only host sync (one 32-byte copy)
+        if early:
+            scalars = model._early_scalars                          # cloned behind the forward on the side stream
+        recon, kld = scalars[1], scalars[2]
         if status != 0:
             raise ValueError(f"batch violates the feature invariants (status bits {status:#x})")
         if host[3] != 0.0:

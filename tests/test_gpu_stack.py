@@ -1,0 +1,57 @@
+"""Chained launches (k_fwd_stack / k_bwd_stack) against one launch per sublayer (DVS_SPLIT_STACK=1): same kernels' phase
+functions, same workgroup -> DAG mapping, so losses, gradients and the parameters after train steps must agree BIT FOR BIT.
+The switch is read once per process, hence the two child processes."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import hashlib, sys
+import torch
+sys.path.insert(0, %(repo)r)
+from oracle import features as ofeat
+from oracle import pace_oracle as po
+from dags_vae_search_amd import PaceVaeV3, LabeledGraph, optim as dopt
+from dags_vae_search_amd.train import train_batch
+cfg = po.PaceConfig(n=12, card=12)
+params = po.init_params(cfg, seed=5)
+m = PaceVaeV3(12, 12, 32, 8, 3, 64, 32, 32, 0.15)
+m.load_state_dict(params)
+m = m.to("cuda:0").train()
+graphs = ofeat.synthetic_dags(12, 12, 1000, seed=7)          # ragged: 1000 DAGs = 125 workgroups of 8
+f = m.prepare_features([LabeledGraph(l, e) for l, e in graphs])
+m.seed(11)
+losses = m.loss_and_grad(f).clone()
+h = hashlib.sha256()
+h.update(losses.cpu().numpy().tobytes())
+h.update(m.flat_grads.cpu().numpy().tobytes())
+opt = dopt.Adam(m.parameters(), lr=1e-3).attach(m)
+for _ in range(3):
+    loss_value, recon, kld = train_batch(f, m, opt)
+h.update(m.flat_params.cpu().numpy().tobytes())
+h.update(repr(loss_value).encode())
+m.eval()
+mu, logvar = m.encode_direct(f)
+h.update(mu.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), loss_value)
+"""
+
+
+def run_child(split: bool) -> str:
+    env = dict(os.environ)
+    env["DVS_SPLIT_STACK"] = "1" if split else "0"
+    out = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    return line
+
+
+def test_chained_and_split_launches_agree_bitwise():
+    chained, split = run_child(False), run_child(True)
+    assert chained == split

@@ -4,6 +4,7 @@ profiles/.  Usage:
     tools/rocprof_summary.py stats  <trace_results.db>                  > profiles/rNN_kernel_stats.csv
     tools/rocprof_summary.py gaps   <trace_results.db>                  (GPU busy / idle per train step)
     tools/rocprof_summary.py timeline <trace_results.db> [step]         (one step: start offset, duration, gap before)
+    tools/rocprof_summary.py hbm-csv <fetch_pass.csv> <write_pass.csv> <batch>   > profiles/rNN_pmc_hbm.csv
     tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   > profiles/rNN_pmc.csv  (per-dispatch averages;
                                                                         from rocprofv3 --pmc ... --output-format csv)
 Counter passes are collected separately (rocprofv3 --kernel-trace --pmc A B ...; gpurun refuses --pmc with --stats)."""
@@ -79,6 +80,25 @@ def pmc_csv(paths):
         print(k + f",{n}," + ",".join(meta[k]) + "," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))
 
 
+def hbm_csv(fetch_path, write_path, batch):
+    """Two --pmc passes (FETCH_SIZE, WRITE_SIZE; both in KB) -> per-kernel HBM traffic per launch and per DAG.
+    FETCH_SIZE is doubled: gfx950 counts its 128-byte read requests as 64 (MI355X_MICROARCH.md, HBM section)."""
+    import csv
+
+    def avg(path, counter):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("k_") and r["Counter_Name"] == counter:
+                acc[k].append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+    fetch, write = avg(fetch_path, "FETCH_SIZE"), avg(write_path, "WRITE_SIZE")
+    print("kernel,fetch_KB_corrected,write_KB,bytes_per_DAG")
+    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
+        f, w = 2 * fetch[k], write.get(k, 0.0)
+        print(f"{k},{f:.0f},{w:.0f},{(f + w) * 1024 / batch:.0f}")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
@@ -87,6 +107,8 @@ if __name__ == "__main__":
         gaps(sys.argv[2])
     elif mode == "timeline":
         timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 8)
+    elif mode == "hbm-csv":
+        hbm_csv(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     elif mode == "pmc-csv":
         pmc_csv(sys.argv[2:])
     else:

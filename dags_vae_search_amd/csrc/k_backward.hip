@@ -82,26 +82,37 @@ void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t
 // ---------------------------------------------------------------------------------------------------------
 // grads[p] = sum over slabs (fixed order)
 // ---------------------------------------------------------------------------------------------------------
+// One workgroup = 64 float4 columns x 4 slab quarters: four times the loads in flight of a thread-per-column walk
+// (the kernel is a 230 MB strided read: 66 -> 51 us; eight ranges: no further gain); the quarters meet in LDS and are
+// added in fixed order.
 __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceArgs a) {
-    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i4 >= a.P) return;
-    const bool fc = (i4 >= a.fc_lo1 && i4 < a.fc_hi1) || (i4 >= a.fc_lo2 && i4 < a.fc_hi2);
-    const float* src = fc ? a.fcpart : a.slab;
-    const int n = fc ? DVS_FC_PARTS : a.nslab;
+    __shared__ f4 part[4][64];
+    const int q = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int64_t i4 = ((int64_t)blockIdx.x * 64 + c) * 4;
+    const bool in = i4 < a.P;
     f4 s = f4_zero();
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {      // 8 independent 16-byte loads in flight per lane
-        f4 v[8];
+    if (in) {
+        const bool fc = (i4 >= a.fc_lo1 && i4 < a.fc_hi1) || (i4 >= a.fc_lo2 && i4 < a.fc_hi2);
+        const float* src = fc ? a.fcpart : a.slab;
+        const int n = fc ? DVS_FC_PARTS : a.nslab;
+        const int per = (n + 3) / 4;
+        const int k1 = (q + 1) * per < n ? (q + 1) * per : n;
+        int k = q * per;
+        for (; k + 8 <= k1; k += 8) {      // 8 independent 16-byte loads in flight per lane
+            f4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const f4*)(src + (size_t)(k + u) * a.P + i4);
+            for (int u = 0; u < 8; ++u) v[u] = *(const f4*)(src + (size_t)(k + u) * a.P + i4);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < k1; ++k) s += *(const f4*)(src + (size_t)k * a.P + i4);
     }
-    for (; k < n; ++k) s += *(const f4*)(src + (size_t)k * a.P + i4);
-    *(f4*)(a.grads + i4) = s;
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && in) *(f4*)(a.grads + i4) = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st) {
     const int64_t n4 = (a.P + 3) / 4;
-    DVS_LAUNCH(k_reduce_slabs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_reduce_slabs, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, a);
 }

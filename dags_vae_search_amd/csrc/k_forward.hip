@@ -6,19 +6,27 @@
 // ---------------------------------------------------------------------------------------------------------
 // dvs_pack_features: reference-layout dense features -> 96-byte records (replaces pace.py:1981-1985's
 // .to(device) hand-over; the features themselves come from prepare_features, pace.py:1345-1478).
-// One thread per (DAG, token slot).
+// One thread per (mask head, DAG, token slot).
 // ---------------------------------------------------------------------------------------------------------
 // A workgroup owns PACK_DAGS consecutive DAGs: their label / position / adjacency rows and their 8 per-head mask
 // copies are four CONTIGUOUS byte ranges of the batched feature tensors, streamed into LDS with 16-byte loads
 // (fully coalesced; the HBM-bound leg of the step: 4.5 KB per DAG at n=12), then one thread per (DAG, token) builds
 // its record fields from LDS.
-constexpr int PACK_DAGS = 16;
+constexpr int PACK_DAGS = 4;     // 18 KB of LDS, 512 threads = (8 mask heads) x (4 DAGs) x (16 tokens)
 __device__ __forceinline__ void pack_stream(float* dst, const float* __restrict__ src, size_t nfloats) {
     const size_t n4 = nfloats >> 2;
-    for (size_t i = threadIdx.x; i < n4; i += blockDim.x) *(f4*)(dst + 4 * i) = *(const f4*)(src + 4 * i);
+    size_t i = threadIdx.x;
+    for (; i + 3 * blockDim.x < n4; i += 4 * blockDim.x) {      // four 16-byte loads in flight per lane
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f4*)(src + 4 * (i + u * blockDim.x));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(f4*)(dst + 4 * (i + u * blockDim.x)) = v[u];
+    }
+    for (; i < n4; i += blockDim.x) *(f4*)(dst + 4 * i) = *(const f4*)(src + 4 * i);
     for (size_t i = 4 * n4 + threadIdx.x; i < nfloats; i += blockDim.x) dst[i] = src[i];
 }
-__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+__global__ __launch_bounds__(8 * 16 * PACK_DAGS) void k_pack(PackArgs a) {
     DVS_DYN_LDS(smem);
     const int N = a.N, C = a.C;
     const int dag0 = blockIdx.x * PACK_DAGS;
@@ -27,16 +35,27 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
     float* s_pos = s_lab + PACK_DAGS * 16 * 16;        // [PACK_DAGS][N][N]
     float* s_adj = s_pos + PACK_DAGS * 16 * 16;
     float* s_msk = s_adj + PACK_DAGS * 16 * 16;        // [PACK_DAGS][8][N][N] bytes, streamed as floats
-    // DAG dag0's blocks start at multiples of 16 DAGs * {N*C, N*N} floats = multiples of 64 bytes: 16-byte loads are legal
+    // DAG dag0's blocks start at multiples of PACK_DAGS = 4 DAGs * {N*C, N*N} floats (8*N*N mask bytes): multiples of 16 bytes
     pack_stream(s_lab, a.lab1h + (size_t)dag0 * N * C, (size_t)nd * N * C);
     pack_stream(s_pos, a.pos1h + (size_t)dag0 * N * N, (size_t)nd * N * N);
     pack_stream(s_adj, a.adj + (size_t)dag0 * N * N, (size_t)nd * N * N);
     pack_stream(s_msk, (const float*)(a.tmask + (size_t)dag0 * 8 * N * N), (size_t)nd * 8 * N * N / 4);
     __syncthreads();
-    const int d = threadIdx.x >> 4, i = threadIdx.x & 15;
+    // thread = (head h, DAG d, token i): head 0 builds the record row, heads 1..7 check that their mask copy equals head 0's
+    const int h = threadIdx.x / (16 * PACK_DAGS), d = (threadIdx.x >> 4) % PACK_DAGS, i = threadIdx.x & 15;
     if (d >= nd) return;
     const uint8_t* msk = (const uint8_t*)s_msk;
     int bad = 0;
+    if (h > 0) {
+        if (i < N) {
+            const uint8_t* m0 = msk + ((size_t)d * 8 * N + i) * N;
+            const uint8_t* mh = msk + (((size_t)d * 8 + h) * N + i) * N;
+            for (int j = 0; j < N; ++j)
+                if ((mh[j] != 0) != (m0[j] != 0)) bad |= 2;
+        }
+        if (bad) atomicOr(a.status, bad);
+        return;
+    }
     int label = 0, pos = 0;
     unsigned parents = 0, allowed = 1u << i;
     if (i < N) {
@@ -61,11 +80,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
         const uint8_t* m0 = msk + ((size_t)d * 8 * N + i) * N;
         for (int j = 0; j < N; ++j)
             if (!m0[j]) allowed |= 1u << j;
-        for (int h = 1; h < 8; ++h) {
-            const uint8_t* mh = msk + (((size_t)d * 8 + h) * N + i) * N;
-            for (int j = 0; j < N; ++j)
-                if ((mh[j] != 0) != (m0[j] != 0)) bad |= 2;
-        }
         if (!((allowed >> i) & 1u)) bad |= 4;
     }
     DvsRecord* r = a.rec + dag0 + d;
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st) {
     const size_t lds = (size_t)PACK_DAGS * (3 * 256 * 4 + 8 * 256);
     DVS_SET_LDS(k_pack, lds);
-    DVS_LAUNCH(k_pack, dim3((a.B + PACK_DAGS - 1) / PACK_DAGS), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_pack, dim3((a.B + PACK_DAGS - 1) / PACK_DAGS), dim3(8 * 16 * PACK_DAGS), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -65,6 +65,25 @@ def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     lab2[0, 0] = card + 5
     assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab2), ptr(pr), ptr(rec_b), ptr(status), None) == 0
     assert status[0] & 1
+    # dvs_pack_features' own checks: a mask head that differs from head 0 -> bit 1; a token that may not attend itself -> bit 2;
+    # a label row that is not one-hot -> bit 0
+    N = n + 3
+
+    def pack_status(lab1h, masks):
+        st = np.zeros(1, np.int32)
+        assert lib.dvs_pack_features(ctypes.byref(shape), ptr(lab1h), ptr(f["vertex_position_features"]),
+                                     ptr(f["adjacency_matrices"]), ptr(masks), ptr(rec_a), ptr(st), None) == 0
+        return int(st[0])
+    tm4 = tm.reshape(B, 8, N, N)
+    head = tm4.copy()
+    head[B - 1, 5, 2, 1] ^= 1
+    assert pack_status(f["vertex_label_features"], np.ascontiguousarray(head.reshape(tm.shape))) == 2
+    diag = tm4.copy()
+    diag[1, :, 3, 3] = 1
+    assert pack_status(f["vertex_label_features"], np.ascontiguousarray(diag.reshape(tm.shape))) == 4
+    half = np.ascontiguousarray(f["vertex_label_features"].copy())
+    half[0, 1] *= 0.5
+    assert pack_status(half, tm) == 1
 
 
 def test_emu_wide_forward_matches_reference_golden():

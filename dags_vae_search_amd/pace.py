@@ -447,6 +447,9 @@ class PaceVaeV3(nn.Module):
         eng = self._eng()
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
             self.bind_flat_grads()        # first step: allocate (also hands the validation word to the engine)
+        if self._early_pending:           # a step whose read_step() never came (exception in between): drain it first, so
+            self._early_pending = False   # that its re-arming of the validation word cannot land behind this step's pack
+            self._ev_tail.synchronize()
         if not packed:
             # defer_check: the validation word is read (and re-armed) by read_step() at the end of the step
             self._pack(features, check=False if defer_check else None, zero_status=not defer_check)

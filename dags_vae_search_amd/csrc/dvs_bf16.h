@@ -162,3 +162,92 @@ __device__ __forceinline__ void dvs_matb3(f4 (&y)[OT], const Split3T& x, const d
         DVS_SCHED_FENCE();
     }
 }
+
+// ---- parked bf16 tiles and transposing LDS reads: cooperative weight gradients on the bf16 pipe -------------------------
+// dW = dY^T X contracts over TOKENS, so an MFMA operand is 8 consecutive tokens of one feature per lane — the transpose of
+// how a tile is parked ([token][feature]).  gfx950's ds_read_b64_tr_b16 delivers exactly that: per 16-lane group it reads a
+// block of 4 rows x 16 columns of 16-bit elements and hands lane i column i of the 4 rows (cdna_hip_programming.md T10).
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+constexpr int DVS_PLD = 68;                  // bf16 per parked row (136 B): a [hi | lo] pair is exactly one fp32 scratch tile (DVS_SCR)
+constexpr int DVS_PKB = 16 * DVS_PLD;        // bf16 elements of one parked part [16 tokens][DVS_PLD]
+
+// park a T-layout tile as hi / lo bf16 images (lo directly behind hi), row-major [token][feature]: 8-byte stores
+__device__ __forceinline__ void dvs_park_bf(dvs_bf16* img, const f4 (&x)[4], const Lane& L) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        bf4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dvs_bf16 hh, ll;
+            dvs_split1(x[t][i], hh, ll);
+            h[i] = hh;
+            l[i] = ll;
+        }
+        *(bf4*)(img + L.r * DVS_PLD + 16 * t + 4 * L.g) = h;
+        *(bf4*)(img + DVS_PKB + L.r * DVS_PLD + 16 * t + 4 * L.g) = l;
+    }
+}
+// lane 4q+p of a 16-lane group passes the address of row q, columns 4p..4p+3 of the block; lane i gets column i, rows 0..3.
+// All 64 lanes must be active.
+__device__ __forceinline__ bf4 dvs_tr_read(const dvs_bf16* p) {
+#ifndef DVS_EMU
+    typedef short s4_ __attribute__((ext_vector_type(4)));
+    const s4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_ __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(bf4, v);
+#else
+    const unsigned long long a = (unsigned long long)p;
+    const int lane = (int)(threadIdx.x & 63), grp = lane & 48, i = lane & 15;
+    bf4 out;
+    for (int q = 0; q < 4; ++q) {
+        const int src = grp + 4 * q + (i >> 2);
+        const unsigned lo = __shfl((unsigned)(a & 0xFFFFFFFFull), src), hi = __shfl((unsigned)(a >> 32), src);
+        const dvs_bf16* row = (const dvs_bf16*)(((unsigned long long)hi << 32) | lo);
+        out[q] = row[i & 3];
+    }
+    return out;
+#endif
+}
+// the lane's 8-token operand slice of feature column fcol0 + r: tokens 8*(g&1) .. +7 of the parked part `tile`
+__device__ __forceinline__ bf8 dvs_tr_frag(const dvs_bf16* tile, int fcol0, const Lane& L) {
+    const dvs_bf16* base = tile + (8 * (L.g & 1) + (L.r >> 2)) * DVS_PLD + fcol0 + 4 * (L.r & 3);
+    const bf4 a = dvs_tr_read(base), b = dvs_tr_read(base + 4 * DVS_PLD);
+    bf8 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[i] = a[i];
+        f[4 + i] = b[i];
+    }
+    return f;
+}
+// Wave d of the workgroup parked dY at abase + d*stride and X at bbase + d*stride (hi part, lo part DVS_PKB behind).
+// acc[it][reg] = dW[16*(wave&3) + 4g + reg][16*it + r] and accb[reg] = sum over tokens of dY[.][16*(wave&3) + 4g + reg] (any
+// column r), both over the 4 DAGs of this wave's group: two K = 32 blocks, each the 16-token tiles of two DAGs.
+__device__ __forceinline__ void dvs_coop_dw_bf(f4 (&acc)[4], f4& accb, const dvs_bf16* abase, const dvs_bf16* bbase, int stride,
+                                               const Lane& L) {
+    const int ot = L.wave & 3, d0 = L.wave & 4;
+    bf8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (dvs_bf16)1.0f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int d = d0 + 2 * m + (L.g >> 1);
+        const dvs_bf16* ta = abase + d * stride;
+        const dvs_bf16* tb = bbase + d * stride;
+        const bf8 ah = dvs_tr_frag(ta, 16 * ot, L), al = dvs_tr_frag(ta + DVS_PKB, 16 * ot, L);
+        accb = dvs_mfma_bf(al, ones, accb);
+        accb = dvs_mfma_bf(ah, ones, accb);
+        bf8 bh[4], bl[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            bh[it] = dvs_tr_frag(tb, 16 * it, L);
+            bl[it] = dvs_tr_frag(tb + DVS_PKB, 16 * it, L);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(al, bh[it], acc[it]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(ah, bl[it], acc[it]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(ah, bh[it], acc[it]);
+        DVS_SCHED_FENCE();
+    }
+}

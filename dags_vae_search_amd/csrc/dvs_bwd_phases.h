@@ -7,8 +7,9 @@
 #include "dvs_backward.h"
 #include "dvs_wimg.h"
 
+constexpr int DVS_PROJB_SLOT = 6 * DVS_PKB;       // bf16 elements per wave: 3 parked tiles [hi | lo]
 static size_t projb_lds_bytes(int nproj) {
-    return (size_t)2 * nproj * 64 * DVS_LDB * sizeof(dvs_bf16) + (128 + (size_t)8 * 3 * DVS_SCR + 16) * 4;
+    return (size_t)2 * nproj * 64 * DVS_LDB * sizeof(dvs_bf16) + 128 * 4 + (size_t)8 * DVS_PROJB_SLOT * sizeof(dvs_bf16) + 64;
 }
 
 
@@ -19,7 +20,7 @@ static size_t projb_lds_bytes(int nproj) {
 struct FfnBLds {
     // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as the bf16x6 triple k_ffn_fwd uses: the hidden is
     // recomputed with the forward's own instruction sequence, because its sign must reproduce the forward's ReLU mask.
-    // The weight GRADIENTS (dvs_coop_dw) stay exact fp32.
+    // The weight gradients run on the bf16 pipe too (dvs_coop_dw_bf: parked bf16 tiles, transposing LDS reads).
     dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl, *W1x6;
     float *b1, *b2, *lg, *lb, *og, *ob, *slots;
 };
@@ -72,7 +73,10 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     float* sB = sA + DVS_SCR;
     DvsGroup G = {gcount + (L.wave >> 2), 0};
     f4 aW1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, aW2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-    float vb1 = 0.f, vb2 = 0.f, vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;    // lane = feature
+    f4 ab1 = f4_zero(), ab2 = f4_zero();                                // bias gradients: rows 16*(wave&3).. like aW1 / aW2
+    float vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;                   // lane = feature
+    dvs_bf16* const bslots = (dvs_bf16*)l.slots;                        // a [hi | lo] bf16 pair fills one fp32 scratch tile
+    constexpr int BSTRIDE = 2 * 2 * DVS_SCR;                            // bf16 elements between the slots of two waves
     for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
         const int dag = base + L.wave;                     // tile index
         const bool live = dag < B;
@@ -117,12 +121,10 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         for (int t = 0; t < 4; ++t) dy[t] = gp[t];
         dvs_dropout_tile(dy, kpost, D, L, T.tok0);
         // ---- dW2 += dy^T hd, db2 += sum dy --------------------------------------------------------------------------
-        dvs_park_T(sA, dy, L);
-        dvs_park_T(sB, hd, L);
-        dvs_wave_sync();
-        vb2 += dvs_colsum(sA, L);
+        dvs_park_bf((dvs_bf16*)sA, dy, L);
+        dvs_park_bf((dvs_bf16*)sB, hd, L);
         dvs_group_barrier(G, L);
-        dvs_coop_dw(aW2, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        dvs_coop_dw_bf(aW2, ab2, bslots, bslots + 2 * DVS_SCR, BSTRIDE, L);
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
         dvs_matb_T<4>(dh, dvs_split_T(dy), l.W2Th, l.W2Tl, 0, L);
         dvs_dropout_tile(dh, khid, D, L, T.tok0);
@@ -132,12 +134,10 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
             for (int kk = 0; kk < 4; ++kk) dh[t][kk] = hpre[t][kk] > 0.f ? dh[t][kk] : 0.f;
         dvs_group_barrier(G, L);
         // ---- dW1 += dh^T x, db1 += sum dh ----------------------------------------------------------------------------
-        dvs_park_T(sA, dh, L);
-        dvs_park_T(sB, x, L);
-        dvs_wave_sync();
-        vb1 += dvs_colsum(sA, L);
+        dvs_park_bf((dvs_bf16*)sA, dh, L);
+        dvs_park_bf((dvs_bf16*)sB, x, L);
         dvs_group_barrier(G, L);
-        dvs_coop_dw(aW1, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        dvs_coop_dw_bf(aW1, ab1, bslots, bslots + 2 * DVS_SCR, BSTRIDE, L);
         f4 dx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] = gp[t];
@@ -162,12 +162,20 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     dvs_coop_store((float*)smem, slab + a.o_l1_w, aW1, L);
     dvs_coop_store((float*)smem, slab + a.o_l2_w, aW2, L);
     float* red = (float*)smem;                        // [8 waves][6][64]
-    red[(L.wave * 6 + 0) * 64 + L.lane] = vb1;
-    red[(L.wave * 6 + 1) * 64 + L.lane] = vb2;
+    red[(L.wave * 6 + 0) * 64 + L.lane] = 0.f;
+    red[(L.wave * 6 + 1) * 64 + L.lane] = 0.f;
     red[(L.wave * 6 + 2) * 64 + L.lane] = vgam;
     red[(L.wave * 6 + 3) * 64 + L.lane] = vbet;
     red[(L.wave * 6 + 4) * 64 + L.lane] = vog;
     red[(L.wave * 6 + 5) * 64 + L.lane] = vob;
+    dvs_wave_sync();
+    if (L.r == 0) {                                   // this wave's 16 features of the bias gradients (dvs_coop_dw_bf)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            red[(L.wave * 6 + 0) * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = ab1[reg];
+            red[(L.wave * 6 + 1) * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = ab2[reg];
+        }
+    }
     __syncthreads();
     if (dvs_tid() < 6 * 64) {
         const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
@@ -189,12 +197,14 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
 template <int NPROJ>
 __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* smem) {
     // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
-    // of the forward depends on it), so it runs on the bf16 matrix pipe; the weight gradients stay exact fp32.
+    // of the forward depends on it), so it runs on the bf16 matrix pipe.  So do the weight gradients dW_p = dY_p^T X: the
+    // tiles are parked as bf16 hi / lo images and read back transposed (dvs_coop_dw_bf); the bias gradients ride along as
+    // products with a ones fragment.
     dvs_bf16* WT = (dvs_bf16*)smem;                // [NPROJ][hi | lo][64][LDB]
     float* lg = (float*)(WT + NPROJ * 2 * DVS_IMG64);
     float* lb = lg + 64;
-    float* slots = lb + 64;                        // per wave 3 tiles: A0, A1 (alternating dY) and B (X)
-    int* gcount = (int*)(slots + 8 * 3 * DVS_SCR);
+    dvs_bf16* slots = (dvs_bf16*)(lb + 64);        // per wave 3 tiles [hi | lo]: A0, A1 (alternating dY) and B (X)
+    int* gcount = (int*)(slots + 8 * DVS_PROJB_SLOT);
     dvs_copy_image(WT, (const dvs_bf16*)a.wimg, (int)(NPROJ * 2 * DVS_IMG64));
     if (a.ln.stats) {
         dvs_stage_vector(lg, a.ln.g, 64);
@@ -204,15 +214,15 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     __syncthreads();
     const Lane L = dvs_lane();
     const int B = a.dims.B * a.dims.NT;              // tiles
-    float* myA0 = slots + L.wave * 3 * DVS_SCR;
-    float* myA1 = myA0 + DVS_SCR;
-    float* myB = myA0 + 2 * DVS_SCR;
+    dvs_bf16* myA0 = slots + L.wave * DVS_PROJB_SLOT;
+    dvs_bf16* myA1 = myA0 + 2 * DVS_PKB;
+    dvs_bf16* myB = myA0 + 4 * DVS_PKB;
     DvsGroup G = {gcount + (L.wave >> 2), 0};
-    f4 aW[NPROJ][4];
-    float vb[NPROJ], vgam = 0.f, vbet = 0.f;
+    f4 aW[NPROJ][4], ab[NPROJ];
+    float vgam = 0.f, vbet = 0.f;
 #pragma unroll
     for (int p = 0; p < NPROJ; ++p) {
-        vb[p] = 0.f;
+        ab[p] = f4_zero();
 #pragma unroll
         for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
     }
@@ -230,29 +240,30 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
 #pragma unroll
             for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
         }
-        dvs_park_T(myB, x, L);
+        dvs_park_bf(myB, x, L);
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
-            float* mine = (p & 1) ? myA1 : myA0;
+            dvs_bf16* mine = (p & 1) ? myA1 : myA0;
             f4 dy[4];
             dvs_load_grad(dy, a.gy[p], dg, Nl, L);
-            dvs_park_T(mine, dy, L);
-            dvs_wave_sync();
-            vb[p] += dvs_colsum(mine, L);
+            dvs_park_bf(mine, dy, L);
             dvs_group_barrier(G, L);
-            dvs_coop_dw(aW[p], slots + (p & 1) * DVS_SCR, slots + 2 * DVS_SCR, 3 * DVS_SCR, L);
+            dvs_coop_dw_bf(aW[p], ab[p], slots + (p & 1) * 2 * DVS_PKB, slots + 4 * DVS_PKB, DVS_PROJB_SLOT, L);
             dvs_matb_T<4>(dx, dvs_split_T(dy), WT + p * 2 * DVS_IMG64, WT + p * 2 * DVS_IMG64 + DVS_IMG64, 0, L);
         }
         dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
         if (a.ln.stats) {
+            // two fp32 tiles for the column sums: each fits the [hi | lo] pair of a parked tile
+            float* fA = (float*)myA0;
+            float* fB = (float*)myB;
             f4 t0[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) t0[t] = dx[t] * xhat[t];
-            dvs_park_T(myA0, t0, L);
-            dvs_park_T(myB, dx, L);
+            dvs_park_T(fA, t0, L);
+            dvs_park_T(fB, dx, L);
             dvs_wave_sync();
-            vgam += dvs_colsum(myA0, L);
-            vbet += dvs_colsum(myB, L);
+            vgam += dvs_colsum(fA, L);
+            vbet += dvs_colsum(fB, L);
             dvs_wave_sync();
             dvs_ln_bwd_core(dx, xhat, rstd, lg, L);
         }
@@ -272,10 +283,18 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
 #pragma unroll
     for (int p = 0; p < NPROJ; ++p) dvs_coop_store((float*)smem, slab + a.o_w + 4096 * p, aW[p], L, so, false);
     float* red = (float*)smem;                        // [8 waves][NPROJ + 2][64]
+    // bias gradients: wave (group, ot) holds the sums of features 16*ot + 4g + reg (every column r the same)
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) red[(L.wave * (NPROJ + 2) + p) * 64 + L.lane] = vb[p];
+    for (int p = 0; p < NPROJ; ++p) red[(L.wave * (NPROJ + 2) + p) * 64 + L.lane] = 0.f;
     red[(L.wave * (NPROJ + 2) + NPROJ) * 64 + L.lane] = vgam;
     red[(L.wave * (NPROJ + 2) + NPROJ + 1) * 64 + L.lane] = vbet;
+    dvs_wave_sync();
+    if (L.r == 0) {
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) red[(L.wave * (NPROJ + 2) + p) * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = ab[p][reg];
+    }
     __syncthreads();
     if (dvs_tid() < (NPROJ + 2) * 64) {
         const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
@@ -401,7 +420,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     DvsGroup G = {l.gcount + (L.wave >> 2), 0};
     const float scale = 0.35355339059327373f;
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-    float vbo = 0.f;
+    f4 abo = f4_zero();                           // d out_proj.bias, rows 16*(wave&3).. like aWo
     for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
         const int dag = base + L.wave;
         const bool live = dag < B;
@@ -447,9 +466,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
             f4 dy[4];
             dvs_load_grad(dy, a.gpre, dg, Nl, L);
             dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
-            dvs_park_T(sA, dy, L);                     // stays parked until the cooperative dWo below
-            dvs_wave_sync();
-            vbo += dvs_colsum(sA, L);
+            dvs_park_bf((dvs_bf16*)sA, dy, L);         // [hi | lo] bf16, stays parked until the cooperative dWo below
 #pragma unroll
             for (int t = 0; t < 4; ++t) dOT[t] = f4_zero();
             dvs_matb_T<4>(dOT, dvs_split_T(dy), l.WoTh, l.WoTl, 0, L);
@@ -529,9 +546,14 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                         oa = dvs_mfma(pT[0][kk] * mk[0][kk], v[t][kk], oa);
                         ob = dvs_mfma(pT[1][kk] * mk[1][kk], v[t][kk], ob);
                     }
-                    float* po = sB + (4 * L.g) * DVS_LD + 16 * t + L.r;
+                    dvs_bf16* po = (dvs_bf16*)sB + (4 * L.g) * DVS_PLD + 16 * t + L.r;       // [hi | lo] bf16 image of O
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) po[reg * DVS_LD] = hsel ? ob[reg] : oa[reg];
+                    for (int reg = 0; reg < 4; ++reg) {
+                        dvs_bf16 oh, ol;
+                        dvs_split1(hsel ? ob[reg] : oa[reg], oh, ol);
+                        po[reg * DVS_PLD] = oh;
+                        po[DVS_PKB + reg * DVS_PLD] = ol;
+                    }
                 }
                 // dP^T = V dO^T
 #pragma unroll
@@ -619,14 +641,19 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         }
         // ---- dWo += dy^T O over the group's DAGs ------------------------------------------------------------------
         dvs_group_barrier(G, L);
-        dvs_coop_dw(aWo, l.slots, l.slots + DVS_SCR, 2 * DVS_SCR, L);
+        dvs_coop_dw_bf(aWo, abo, (const dvs_bf16*)l.slots, (const dvs_bf16*)l.slots + 2 * DVS_SCR, 2 * 2 * DVS_SCR, L);
         dvs_group_barrier(G, L);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
     dvs_coop_store((float*)smem, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
     float* red = (float*)smem;
-    red[L.wave * 64 + L.lane] = vbo;
+    red[L.wave * 64 + L.lane] = 0.f;
+    dvs_wave_sync();
+    if (L.r == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[L.wave * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = abo[reg];
+    }
     __syncthreads();
     if (dvs_tid() < 64) {
         float s = 0.f;

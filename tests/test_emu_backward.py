@@ -93,8 +93,8 @@ def test_emu_train0_golden_and_adam_step():
         new = p[off:off + n].reshape(shp)
         ref = tr.P[name].detach().numpy()
         g = grads[name] * min(1.0, 1.0 / (gn + 1e-6))
-        big = np.abs(g) > 1e-5
-        assert np.abs(new - ref).max() < 3e-5
+        big = np.abs(g) > 1e-7          # below that the direction of Adam's first move is rounding noise (see the GPU twin)
+        assert np.abs(new - ref).max() < 2.01e-4
         if big.any():
             worst_big = max(worst_big, float(np.abs(new - ref)[big].max()))
     assert worst_big < 1e-6

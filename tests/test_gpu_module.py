@@ -50,14 +50,18 @@ def test_train_mode_dropout0_injected_eps_and_one_step(name):
     coef = min(1.0, 1.0 / (gn + 1e-6))
 
     def check_step(model):
-        worst_big = 0.0
+        # Adam's first step moves every parameter by lr * g / (|g| + 1e-8): entries whose clipped gradient is above 1e-7
+        # must land on the reference's value (measured: 1.4e-7); below that the step direction is rounding noise in ANY
+        # implementation — e.g. the key bias of every attention, whose true gradient is exactly zero (softmax shift
+        # invariance) — and only the size of the move is bounded (at most 2 lr apart).
+        worst = 0.0
         for k, p in model.state_dict().items():
             err = np.abs(p.cpu().numpy() - z["step/param/" + k])
-            big = np.abs(z["train0/grad/" + k]) * coef > 1e-5
-            assert err.max() < 3e-5, k
-            if big.any():
-                worst_big = max(worst_big, float(err[big].max()))
-        assert worst_big < 1e-6
+            sure = np.abs(z["train0/grad/" + k]) * coef > 1e-7
+            assert err.max() < 2.01e-4, k
+            if sure.any():
+                worst = max(worst, float(err[sure].max()))
+        assert worst < 1e-6
 
     # (a) reference sequence with a stock optimiser
     model = build_model(cfg, params, dropout=0.0).train()

@@ -227,8 +227,9 @@ __device__ __forceinline__ void dvs_ln_bwd(f4 (&dx)[4], const f4 (&xhat)[4], flo
 // (waves 0-3 and 4-7; a SIMD hosts one wave of each, so the groups' instruction streams interleave on every SIMD).
 // Every wave parks the two operand tiles of its DAG row-major ([token][feature], stride DVS_LD) in its LDS slots, the
 // group synchronises on its own LDS counter (an s_barrier would lock both groups into the same phase and forfeit the
-// MFMA/VALU overlap), and wave w accumulates rows 16*(w&3).. of dW over the 4 DAGs of its group: same MFMA count,
-// 16 accumulator registers per matrix instead of 64.
+// MFMA/VALU overlap), and wave w accumulates rows 16*(w&3).. of dW over the 4 DAGs of its group: 16 accumulator
+// registers per matrix instead of 64.  The product itself runs on the bf16 pipe from bf16 hi / lo parked tiles read back
+// transposed (dvs_coop_dw_bf, dvs_bf16.h).
 struct DvsGroup {
     int* counter;      // LDS word of this wave's group
     int target;        // arrivals expected at the next barrier
@@ -248,23 +249,6 @@ __device__ __forceinline__ void dvs_group_barrier(DvsGroup& G, const Lane& L) {
         __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
-}
-// Wave d's dY tile is at abase + d*stride, its X tile at bbase + d*stride (floats);
-// acc[it][reg] = dW[16*(wave&3) + 4g + reg][16*it + r], summed over the DAGs of this wave's group.
-__device__ __forceinline__ void dvs_coop_dw(f4 (&acc)[4], const float* abase, const float* bbase, int stride, const Lane& L) {
-    const int ot = L.wave & 3, d0 = L.wave & 4;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const float* sa = abase + (d0 + d) * stride + (4 * L.g) * DVS_LD + L.r;
-        const float* sb = bbase + (d0 + d) * stride + (4 * L.g) * DVS_LD + L.r;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float av = sa[kk * DVS_LD + 16 * ot];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma(av, sb[kk * DVS_LD + 16 * it], acc[it]);
-        }
-        DVS_SCHED_FENCE();
-    }
 }
 // park a T-layout tile row-major in a slot
 __device__ __forceinline__ void dvs_park_T(float* slot, const f4 (&v)[4], const Lane& L) {

@@ -45,10 +45,10 @@ static size_t ffnb_lds_bytes() {
 }
 
 // 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
-// (dvs_coop_dw): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
-// The two gradient products (d hidden, d x) run on the bf16 matrix pipe as bf16x3: gradient
-// parity is bounded at 2e-3 of the tensor maximum (tests), three orders of magnitude above their ~1e-5 error, whereas
-// the forward keeps exact fp32 MFMAs for the 1e-4 ELBO contract.
+// (dvs_coop_dw_bf): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
+// The gradient products (d hidden, d x, and the weight gradients) run on the bf16 matrix pipe as bf16x3: gradient
+// parity is bounded at 2e-3 of the tensor maximum (tests), two orders of magnitude above their ~1e-5 error, whereas
+// the forward keeps fp32-accurate bf16x6 products for the 1e-4 ELBO contract and the hidden is recomputed with them.
 __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* smem) {
     const FfnBLds l = ffnb_lds(smem);
     dvs_copy_image(l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
@@ -191,7 +191,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
 //   dX^T = sum_p W_p^T dY_p^T (+ residual) ; dW_p += dY_p(N) (x) X(N) ; db_p += sum_tok dY_p ; then the producing
 //   sublayer's LayerNorm backward.  Used for self-attention (NPROJ=3), cross-attention q (1) and k,v (2, X = memory).
 // ---------------------------------------------------------------------------------------------------------
-// 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw):
+// 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw_bf):
 // per wave 16 accumulator registers per projection, ~130 VGPRs, two waves per SIMD.  LDS slots per wave: X (kept for
 // all projections of the DAG) and two alternating dY slots, so one group barrier per projection + one per DAG.
 template <int NPROJ>

@@ -1,3 +1,6 @@
+"""Diagnostic (run on the GPU box from the repo root): per-parameter error of one fused clip + Adam step against the
+reference's golden step, split by the size of the clipped gradient — shows which entries move on rounding noise (the
+key biases of the attentions, whose true gradient is exactly zero) and the relative gradient error per tensor."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from tests.helpers import load_golden

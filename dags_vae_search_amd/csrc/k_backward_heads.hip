@@ -469,12 +469,13 @@ void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {
 // Latent block backward, part 2: weight gradients of fc1/fc2/fc3 — batch-contraction GEMMs over ALL DAGs.
 //   dWfc[o][col(k')] = sum_dag dout[dag][o] X[dag][k'] ;  dW3[row(k')][o] = sum_dag dmem[dag][k'] z[dag][o]
 // Workgroup (mg, q): 4 consecutive output column tiles (64 frag columns k') x batch part q (DVS_FC_PARTS parts); its
-// 4 waves split the part's DAGs, meet in LDS (fixed order) and write one partial per part to fcpart[q][param offset];
+// 8 waves split the part's DAGs (two waves per SIMD: the contraction walk is a chain of load batches and MFMAs, latency-
+// bound with one), meet in LDS (fixed order: w + (w+4), then 0..3) and write one partial per part to fcpart[q][param offset];
 // k_reduce_slabs adds the parts.  Per 4-DAG contraction step a lane issues 14 loads for 24 MFMAs; the [dag][64]
 // dout / [dag][32] z operands are shared by all column tiles (L2).  Bias gradients ride along as column sums.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int FC_MT = 4;     // column tiles per workgroup
-__global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
+__global__ __launch_bounds__(512) void k_fc_dw(FcDwArgs a) {
     __shared__ f4 red[4][FC_MT * 6 + 2][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
     const int mg = blockIdx.x % nmg, q = blockIdx.x / nmg;
     const size_t dstride = (size_t)a.dims.NT * DVS_TILE;
     const int per_q = (B + DVS_FC_PARTS - 1) / DVS_FC_PARTS;
-    const int per_w = (per_q + 3) / 4;
+    const int per_w = (per_q + 7) / 8;
     const int d0 = q * per_q + L.wave * per_w;
     int d1 = d0 + per_w;
     if (d1 > (q + 1) * per_q) d1 = (q + 1) * per_q;
@@ -529,16 +530,33 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
     for (int j = 0; j < FC_MT; ++j) bs3[j] = dvs_sum_g(bs3[j]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) bsfc[t] = dvs_sum_g(bsfc[t]);
+    // waves 0..3 park their partials, waves 4..7 add theirs on top (wave w + 4 onto wave w's)
+    if (L.wave < 4) {
 #pragma unroll
-    for (int j = 0; j < FC_MT; ++j) {
+        for (int j = 0; j < FC_MT; ++j) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) red[L.wave][6 * j + t][L.lane] = acc[j][t];
-        red[L.wave][6 * j + 4][L.lane] = acc3[j][0];
-        red[L.wave][6 * j + 5][L.lane] = acc3[j][1];
+            for (int t = 0; t < 4; ++t) red[L.wave][6 * j + t][L.lane] = acc[j][t];
+            red[L.wave][6 * j + 4][L.lane] = acc3[j][0];
+            red[L.wave][6 * j + 5][L.lane] = acc3[j][1];
+        }
+        red[L.wave][6 * FC_MT][L.lane] = bsfc;
+        red[L.wave][6 * FC_MT + 1][L.lane] = bs3;
     }
-    red[L.wave][6 * FC_MT][L.lane] = bsfc;
-    red[L.wave][6 * FC_MT + 1][L.lane] = bs3;
     __syncthreads();
+    if (L.wave >= 4) {
+        const int w = L.wave - 4;
+#pragma unroll
+        for (int j = 0; j < FC_MT; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[w][6 * j + t][L.lane] += acc[j][t];
+            red[w][6 * j + 4][L.lane] += acc3[j][0];
+            red[w][6 * j + 5][L.lane] += acc3[j][1];
+        }
+        red[w][6 * FC_MT][L.lane] += bsfc;
+        red[w][6 * FC_MT + 1][L.lane] += bs3;
+    }
+    __syncthreads();
+    if (L.wave >= 4) return;
     // wave w finalises column tile j = w
     const int j = L.wave;
     const int m = FC_MT * mg + j;
@@ -594,5 +612,5 @@ __global__ __launch_bounds__(256) void k_fc_dw(FcDwArgs a) {
 }
 
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st) {
-    DVS_LAUNCH(k_fc_dw, dim3(16 * a.dims.NT * DVS_FC_PARTS), dim3(256), 0, st, a);
+    DVS_LAUNCH(k_fc_dw, dim3(16 * a.dims.NT * DVS_FC_PARTS), dim3(512), 0, st, a);
 }

@@ -387,6 +387,12 @@ static void prepare_images(const DvsLayout& L, bool wide, const float* params, f
         attn(L.dec[i].ca, blk_dec_cross(i));
         ffn(L.dec[i].ff, blk_dec_ffn(i));
     }
+    if (!wide) {                 // loss head (one-tile kernels): the two halves of add_edge.0.weight [64][128]
+        add(L.edge0_w, DVS_WIMG_LOSS + DvsLossImg::Wa, 64, 8);
+        add(L.edge0_w + 64, DVS_WIMG_LOSS + DvsLossImg::Wb, 64, 8);
+        add(L.edge0_w, DVS_WIMG_LOSS + DvsLossImg::WaT, 64, 8 | 1);
+        add(L.edge0_w + 64, DVS_WIMG_LOSS + DvsLossImg::WbT, 64, 8 | 1);
+    }
     dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), st);
 }
 static inline const void* wimg_attn(const float* ws, const DvsWorkspace& W, int block) {
@@ -557,6 +563,7 @@ LossArgs dvs_loss_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace&
     a.edge0_b = P + L.edge0_b;
     a.edge2_w = P + L.edge2_w;
     a.edge2_b = P + L.edge2_b;
+    a.wimg = (const dvs_bf16*)(ws + W.wimg) + DVS_WIMG_LOSS;
     a.dag_loss = ws + W.dag_loss;
     return a;
 }

@@ -80,6 +80,7 @@ struct LossArgs {
     const float* xin;
     DvsLN ln;
     const float *node0_w, *node0_b, *node2_w, *node2_b, *edge0_w, *edge0_b, *edge2_w, *edge2_b;
+    const void* wimg;            // loss image block (dvs_wimg.h: DvsLossImg); one-tile kernels
     float* dag_loss;             // [B][2]; NLL goes to [.][0]
     // backward only
     const float* gcoef;          // device [2]

@@ -12,6 +12,9 @@
 //                     WinT  x3 [3 proj][2][64][LDB]                     (k_proj_bwd: dX^T = W_p^T dY_p^T)
 //   FFN block       : W1 x6 [3][64][LDB], W2 x6 [3][64][LDB]            (k_ffn_fwd; W1 also k_ffn_bwd's hidden recompute)
 //                     W2T x3 [2][64][LDB], W1T x3 [2][64][LDB]          (k_ffn_bwd)
+//   loss block      : Wa, Wb x6 [3][64][LDB] each (the two 64-column halves of add_edge.0.weight: k_loss_fwd and
+//                     k_loss_bwd's recompute — the sign of Wa h_i + Wb h_j + b is a ReLU mask, so both use the same
+//                     bf16x6 sequence), WaT, WbT x3 [2][64][LDB] (k_loss_bwd: d h)
 #pragma once
 #include "dvs_bf16.h"
 
@@ -30,15 +33,23 @@ struct DvsFfnImg {
     static constexpr size_t W1T = 8 * DVS_IMG64;
     static constexpr size_t SIZE = 10 * DVS_IMG64;
 };
-// blocks of one step: encoder layer i -> attention block 3i ... see dvs_api.hip (img_enc_attn etc.)
+struct DvsLossImg {
+    static constexpr size_t Wa = 0;
+    static constexpr size_t Wb = 3 * DVS_IMG64;
+    static constexpr size_t WaT = 6 * DVS_IMG64;
+    static constexpr size_t WbT = 8 * DVS_IMG64;
+    static constexpr size_t SIZE = 10 * DVS_IMG64;
+};
+// blocks of one step: encoder layer i -> attention block 3i ... see dvs_api.hip (img_enc_attn etc.); the loss block is last
 constexpr int DVS_N_ATTN_BLOCKS = 9, DVS_N_FFN_BLOCKS = 6;
-constexpr size_t DVS_WIMG_BF16 = DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + DVS_N_FFN_BLOCKS * DvsFfnImg::SIZE;
+constexpr size_t DVS_WIMG_LOSS = DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + DVS_N_FFN_BLOCKS * DvsFfnImg::SIZE;
+constexpr size_t DVS_WIMG_BF16 = DVS_WIMG_LOSS + DvsLossImg::SIZE;
 
 struct DvsImgJob {
     int64_t src;                 // float offset of the matrix in the flat parameter buffer
     int64_t dst;                 // bf16 offset of the image (first part) in the image buffer
     int32_t rows;                // source rows (64 columns)
-    int32_t flags;               // bit 0: transposed x3 (else x6 rows); bit 1: rperm; bit 2: cperm
+    int32_t flags;               // bit 0: transposed x3 (else x6 rows); bit 1: rperm; bit 2: cperm; bit 3: source rows are 128 floats apart
 };
 constexpr int DVS_MAX_IMG_JOBS = 96;
 struct DvsImgJobs {

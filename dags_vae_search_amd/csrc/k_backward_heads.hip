@@ -1,20 +1,25 @@
 // Backward of the loss head, the embedding, and the latent block (fc1/fc2/fc3).
 #include "dvs_backward.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Loss head backward (autograd of pace.py:1880-1972) fused with the last decoder LayerNorm's backward.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LOSS_LDN2 = 36;
 struct LossBLds {
-    float *Wn1, *Wn2, *Wa, *Wb, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *scr;
+    dvs_bf16 *Wa, *Wb;           // bf16x6 triples (recompute of U, V exactly as k_loss_fwd)
+    dvs_bf16 *WaT, *WbT;         // bf16x3 pairs of the transposes (d h)
+    float *Wn1, *Wn2, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *scr;
 };
 __device__ __forceinline__ LossBLds lossb_lds(char* smem) {
     LossBLds l;
-    l.Wn1 = (float*)smem;
+    l.Wa = (dvs_bf16*)smem;
+    l.Wb = l.Wa + 3 * DVS_IMG64;
+    l.WaT = l.Wb + 3 * DVS_IMG64;
+    l.WbT = l.WaT + 2 * DVS_IMG64;
+    l.Wn1 = (float*)(l.WbT + 2 * DVS_IMG64);
     l.Wn2 = l.Wn1 + 32 * DVS_LD;
-    l.Wa = l.Wn2 + 16 * LOSS_LDN2;
-    l.Wb = l.Wa + 64 * DVS_LD;
-    l.bn1 = l.Wb + 64 * DVS_LD;
+    l.bn1 = l.Wn2 + 16 * LOSS_LDN2;
     l.bn2 = l.bn1 + 32;
     l.be1 = l.bn2 + 16;
     l.w2 = l.be1 + 64;
@@ -34,8 +39,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         const int c = i >> 5, k = i & 31;
         l.Wn2[c * LOSS_LDN2 + k] = c < C ? a.node2_w[c * 32 + k] : 0.f;
     }
-    dvs_stage_matrix(l.Wa, DVS_LD, a.edge0_w, 128, 64, 64);
-    dvs_stage_matrix(l.Wb, DVS_LD, a.edge0_w + 64, 128, 64, 64);
+    dvs_copy_image(l.Wa, (const dvs_bf16*)a.wimg + DvsLossImg::Wa, (int)DvsLossImg::SIZE);     // the whole loss block, in image order
     dvs_stage_vector(l.bn1, a.node0_b, 32);
     for (int i = threadIdx.x; i < 16; i += blockDim.x) l.bn2[i] = i < C ? a.node2_b[i] : 0.f;
     dvs_stage_vector(l.be1, a.edge0_b, 64);
@@ -133,8 +137,11 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
             w2v[t] = dvs_vecT(l.w2, t, L);
             dU[t] = dV[t] = f4_zero();
         }
-        dvs_mat_T<4, 4>(U, h, l.Wa, DVS_LD, 0, L);
-        dvs_mat_T<4, 4>(V, h, l.Wb, DVS_LD, 0, L);
+        {   // k_loss_fwd's own bf16x6 sequence, bit for bit: the sign of U_i + V_j is the ReLU mask
+            const Split3T hs = dvs_split3_T(h);
+            dvs_matb3<4>(U, hs, l.Wa, 64, 0, L);
+            dvs_matb3<4>(V, hs, l.Wb, 64, 0, L);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             *(f4*)(scrV + L.r * DVS_LD + 16 * t + 4 * L.g) = V[t];
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         dvs_t2n<4>(dVN, dV, scrV, L);
         dvs_outer_acc<4, 4>(dWa, dUN, hN);
         dvs_outer_acc<4, 4>(dWb, dVN, hN);
-        dvs_mat_Tt<4, 4>(dh, dU, l.Wa, DVS_LD, 0, L);
-        dvs_mat_Tt<4, 4>(dh, dV, l.Wb, DVS_LD, 0, L);
+        dvs_matb_T<4>(dh, dvs_split_T(dU), l.WaT, l.WaT + DVS_IMG64, 0, L);       // d h += Wa^T dU + Wb^T dV (bf16x3: smooth)
+        dvs_matb_T<4>(dh, dvs_split_T(dV), l.WbT, l.WbT + DVS_IMG64, 0, L);
         dvs_ln_bwd(dh, xhat, rstd, l.lg, dgam, dbet, L);
         dvs_store_tile(a.gout, dag, dh, L);
     }
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
 }
 
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = dvs_loss_lds_floats(4, 3) * 4;
+    size_t lds = (dvs_loss_lds_floats(4, 3) + 4 * DVS_IMG64 / 2) * 4;        // + the two transposed x3 pairs
     const size_t red = (2 * DVS_RED_MAT) * 4;
     if (lds < red) lds = red;
     DVS_SET_LDS(k_loss_bwd, lds);

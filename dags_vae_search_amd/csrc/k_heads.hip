@@ -1,5 +1,6 @@
 // Latent block (fc1/fc2 -> reparameterize -> KL -> fc3), loss head (node NLL + edge BCE) and loss finalisation.
 #include "dvs_kernels.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Latent block forward (pace.py:1639-1641, 1649-1664, 1997, 2030).  One wave owns 16 DAGs:
@@ -127,15 +128,16 @@ void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LOSS_LDN2 = 36;
 struct LossLds {
-    float *Wn1, *Wn2, *Wa, *Wb, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *scr;
+    dvs_bf16 *Wa, *Wb;           // bf16x6 image triples of the two halves of add_edge.0.weight (dvs_wimg.h)
+    float *Wn1, *Wn2, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *scr;
 };
 __device__ __forceinline__ LossLds loss_lds(char* smem) {
     LossLds l;
-    l.Wn1 = (float*)smem;
+    l.Wa = (dvs_bf16*)smem;
+    l.Wb = l.Wa + 3 * DVS_IMG64;
+    l.Wn1 = (float*)(l.Wb + 3 * DVS_IMG64);
     l.Wn2 = l.Wn1 + 32 * DVS_LD;
-    l.Wa = l.Wn2 + 16 * LOSS_LDN2;
-    l.Wb = l.Wa + 64 * DVS_LD;
-    l.bn1 = l.Wb + 64 * DVS_LD;
+    l.bn1 = l.Wn2 + 16 * LOSS_LDN2;
     l.bn2 = l.bn1 + 32;
     l.be1 = l.bn2 + 16;
     l.w2 = l.be1 + 64;
@@ -145,8 +147,8 @@ __device__ __forceinline__ LossLds loss_lds(char* smem) {
     l.scr = l.lb + 64;
     return l;
 }
-size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave) {
-    return 32 * DVS_LD + 16 * LOSS_LDN2 + 128 * DVS_LD + 32 + 16 + 64 + 64 + 16 + 128 + (size_t)nwaves * tiles_per_wave * DVS_SCR;
+size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave) {      // forward layout: the two x6 image triples first
+    return 6 * DVS_IMG64 / 2 + 32 * DVS_LD + 16 * LOSS_LDN2 + 32 + 16 + 64 + 64 + 16 + 128 + (size_t)nwaves * tiles_per_wave * DVS_SCR;
 }
 
 __device__ __forceinline__ void loss_stage(const LossLds& l, const LossArgs& a) {
@@ -156,8 +158,7 @@ __device__ __forceinline__ void loss_stage(const LossLds& l, const LossArgs& a) 
         const int c = i >> 5, k = i & 31;
         l.Wn2[c * LOSS_LDN2 + k] = c < C ? a.node2_w[c * 32 + k] : 0.f;
     }
-    dvs_stage_matrix(l.Wa, DVS_LD, a.edge0_w, 128, 64, 64);
-    dvs_stage_matrix(l.Wb, DVS_LD, a.edge0_w + 64, 128, 64, 64);
+    dvs_copy_image(l.Wa, (const dvs_bf16*)a.wimg + DvsLossImg::Wa, (int)(6 * DVS_IMG64));      // Wa, Wb triples
     dvs_stage_vector(l.bn1, a.node0_b, 32);
     for (int i = threadIdx.x; i < 16; i += blockDim.x) l.bn2[i] = i < C ? a.node2_b[i] : 0.f;
     dvs_stage_vector(l.be1, a.edge0_b, 64);
@@ -214,8 +215,11 @@ __global__ __launch_bounds__(512) void k_loss_fwd(LossArgs a) {
             V[t] = dvs_vecT(l.be1, t, L);
             w2v[t] = dvs_vecT(l.w2, t, L);
         }
-        dvs_mat_T<4, 4>(U, h, l.Wa, DVS_LD, 0, L);
-        dvs_mat_T<4, 4>(V, h, l.Wb, DVS_LD, 0, L);
+        {   // fp32-accurate bf16x6 products; k_loss_bwd recomputes U, V with the same sequence (their sum's sign is a ReLU mask)
+            const Split3T hs = dvs_split3_T(h);
+            dvs_matb3<4>(U, hs, l.Wa, 64, 0, L);
+            dvs_matb3<4>(V, hs, l.Wb, 64, 0, L);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) *(f4*)(scr + L.r * DVS_LD + 16 * t + 4 * L.g) = V[t];
         dvs_wave_sync();

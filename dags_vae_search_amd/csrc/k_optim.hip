@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
     for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) {
         const int row = 16 * slice + (i >> 6), col = i & 63;
         if (row >= J.rows) break;
-        const float v = src[(size_t)(rperm ? dvs_pi(row) : row) * 64 + (cperm ? dvs_pi(col) : col)];
+        const float v = src[(size_t)(rperm ? dvs_pi(row) : row) * ((J.flags & 8) ? 128 : 64) + (cperm ? dvs_pi(col) : col)];
         if (!transposed) {                       // x6: [3][rows][LDB], img[row][kperm(col)]
             dvs_bf16 h, m, l;
             dvs_split3_1(v, h, m, l);

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         dvs_wave_sync();
         const unsigned par = rec->parents[(L.r + 1) & 15];
         // pass 1: lane r = i walks j; accumulates dU, dw2, db2; publishes d logit(i, j)
+#pragma unroll 2
         for (int j = 0; j < N - 2; ++j) {
             f4 pre[4];
             float e = 0.f;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
         }
         dvs_wave_sync();
         // pass 2: lane r = j walks i; accumulates dV
+#pragma unroll 2
         for (int i = 1; i <= N - 2; ++i) {
             const float dl = (L.r < i) ? dlm[i * 16 + L.r] : 0.f;
 #pragma unroll

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512) void k_loss_fwd(LossArgs a) {
         dvs_wave_sync();
         const unsigned par = rec->parents[(L.r + 1) & 15];
         float enll = 0.f;
+#pragma unroll 2
         for (int j = 0; j < N - 2; ++j) {
             float e = 0.f;
 #pragma unroll

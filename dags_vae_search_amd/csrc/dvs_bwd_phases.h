@@ -320,7 +320,7 @@ struct AttnBLds {
     float *inb, *outb, *lg, *lb, *slots, *stats;
     // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
     // ~1e-5 perturbation stays a ~1e-5 perturbation of the gradient; the FFN's hidden, whose SIGN is a mask, is recomputed
-    // in exact fp32 instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
+    // with the forward's own bf16x6 sequence instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
     dvs_bf16 *Winh, *Winl, *WoTh, *WoTl;
     int* gcount;
 };

@@ -81,9 +81,20 @@ __device__ __forceinline__ void dvs_copy_image(dvs_bf16* dst, const dvs_bf16* __
 #pragma unroll
         for (int u = 0; u < 8; ++u) d[j[u]] = v[u];
     }
-    for (; i < n16; i += step) {
-        int j = i + rot;
-        j = j >= n16 ? j - n16 : j;
-        d[j] = s[j];
+    // the tail (up to 7 chunks per thread) as one predicated batch too: a load -> store tail loop pays a full L2 round trip
+    // per iteration — 5-6 of them for the 108 KB attention-forward block on 512 threads
+    if (i < n16) {
+        f4 v[7];
+        int j[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int k = i + u * step;
+            j[u] = k + rot;
+            j[u] = j[u] >= n16 ? j[u] - n16 : j[u];
+            if (k < n16) v[u] = s[j[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+            if (i + u * step < n16) d[j[u]] = v[u];
     }
 }

@@ -462,8 +462,9 @@ struct FwdChain {
     }
 };
 
+// dec_embed: also write the decoder-side embedding (slot 7, dropout sites 2 / 3) from the same launch (one-tile path)
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
-                            const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st) {
+                            const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st, bool dec_embed = false) {
     EmbedArgs e;
     memset(&e, 0, sizeof(e));
     e.dims = d;
@@ -474,6 +475,10 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
     e.lab_b = P + L.lab_b;
     e.out = ws + W.act[0];
     e.site = 0;
+    if (dec_embed) {
+        e.out2 = ws + W.act[7];
+        e.site2 = 2;
+    }
     launch_embed_fwd(e, grid, st);
     FwdChain chain(grid, 0, st);
     DvsLN ln = {nullptr, nullptr, nullptr};
@@ -648,13 +653,14 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
     const FwdGrids grid = fwd_grids(d, is_wide(s));
 
     prepare_images(L, grid.wide, params, ws, W, st);
-    encoder_forward(d, L, W, rec, params, ws, grid, st);
+    const bool fused_dec_embed = d.drop.on && !grid.wide;
+    encoder_forward(d, L, W, rec, params, ws, grid, st, fused_dec_embed);
     dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
 
     // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
     // only to redraw the dropout masks)
-    int dec_in = 0;
-    if (d.drop.on) {
+    int dec_in = fused_dec_embed ? 7 : 0;
+    if (d.drop.on && !fused_dec_embed) {
         EmbedArgs e;
         memset(&e, 0, sizeof(e));
         e.dims = d;

@@ -31,6 +31,8 @@ struct EmbedArgs {
     const float *W1, *W2, *lab_w, *lab_b;
     float* out;                  // [B][1024] frag order
     int site;                    // dropout site of the first dropout (second = site + 1)
+    float* out2;                 // optional second embedding of the same graphs under dropout sites (site2, site2 + 1):
+    int site2;                   // the decoder-side input of a train-mode step (one-tile forward kernel only)
     // backward only
     const float* gout;           // d out
     float* slab;                 // this kernel's slab base: [grid][P]

@@ -231,39 +231,47 @@ __global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a) {
         const DvsRecord* rec = a.rec + dag;
         const bool valid = L.r < N;
         const EmbSel sel = dvs_emb_selectors(rec, N, scr, L);
-        f4 e1[4];
-        dvs_emb_hidden(e1, l.W1, N, sel, L);
+        f4 eh[4];
+        dvs_emb_hidden(eh, l.W1, N, sel, L);
         const uint32_t gdag = a.dims.dag_offset + dag;
-        dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site, gdag), D, L);
-        f4 x[4];
-        // positional half: e2^T[32 x tok] = W2^T e1^T  (A = W2 column fragments)
-        f4 e2[2] = {f4_zero(), f4_zero()};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f4 w0 = dvs_wcol(l.W2, EMB_LDW2, 0, t, L), w1 = dvs_wcol(l.W2, EMB_LDW2, 16, t, L);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                e2[0] = dvs_mfma(w0[kk], e1[t][kk], e2[0]);
-                e2[1] = dvs_mfma(w1[kk], e1[t][kk], e2[1]);
-            }
-        }
-        {
-            f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
-            dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L);
-            x[2] = tmp[0];
-            x[3] = tmp[1];
-        }
-        // label half
         const int label = rec->label[L.r];
+        // selectors and hidden layer are shared; the encoder-side and (train mode) decoder-side embeddings differ only in
+        // their dropout sites
+        for (int v = 0; v < (a.out2 ? 2 : 1); ++v) {
+            const int site = v ? a.site2 : a.site;
+            f4 e1[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 4; ++t) e1[t] = eh[t];
+            dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site, gdag), D, L);
+            f4 x[4];
+            // positional half: e2^T[32 x tok] = W2^T e1^T  (A = W2 column fragments)
+            f4 e2[2] = {f4_zero(), f4_zero()};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int f = 16 * t + 4 * L.g + kk;
-                x[t][kk] = valid ? fmaxf(l.labw[f * 16 + label] + l.labb[f], 0.f) : 0.f;
+            for (int t = 0; t < 4; ++t) {
+                const f4 w0 = dvs_wcol(l.W2, EMB_LDW2, 0, t, L), w1 = dvs_wcol(l.W2, EMB_LDW2, 16, t, L);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    e2[0] = dvs_mfma(w0[kk], e1[t][kk], e2[0]);
+                    e2[1] = dvs_mfma(w1[kk], e1[t][kk], e2[1]);
+                }
             }
-        if (!valid) { x[2] = f4_zero(); x[3] = f4_zero(); }
-        dvs_store_tile(a.out, dag, x, L);
+            {
+                f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
+                dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L);
+                x[2] = tmp[0];
+                x[3] = tmp[1];
+            }
+            // label half
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int f = 16 * t + 4 * L.g + kk;
+                    x[t][kk] = valid ? fmaxf(l.labw[f * 16 + label] + l.labb[f], 0.f) : 0.f;
+                }
+            if (!valid) { x[2] = f4_zero(); x[3] = f4_zero(); }
+            dvs_store_tile(v ? a.out2 : a.out, dag, x, L);
+        }
     }
 }
 

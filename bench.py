@@ -151,8 +151,8 @@ def cpu_baseline(graphs, feats, steps: int = 3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="DAGs per GPU (default: the workload's)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="n12",
                     help="n12 = the BASELINE metric shape (default); the others are the remaining BASELINE configs")

@@ -18,6 +18,8 @@ MAX_TOKENS = 48           # 16 on the one-tile path (a wavefront owns a DAG); up
 TILE_TOKENS = 16
 DECODE_STATE_BYTES = 440
 RECORD_BYTES = 96         # one-tile path; record_bytes(lib, shape) gives the size that applies
+LOSS_FLOATS = 5           # DVS_LOSS_FLOATS: total, recon, kld, non-finite flag, invalid-features flag
+ABI_VERSION = 200         # DVS_VERSION of include/dvs.h this binding was written against
 
 
 class DvsShape(Structure):
@@ -45,18 +47,30 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_record_bytes.restype = c_size_t
     lib.dvs_record_bytes.argtypes = [P(DvsShape)]
     lib.dvs_pack_features.restype = c_int
-    lib.dvs_pack_features.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    # (shape, label 1-hot, position 1-hot, adjacency, target masks, records, records_bytes, status, stream)
+    lib.dvs_pack_features.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                      c_void_p]
     lib.dvs_build_records.restype = c_int
-    lib.dvs_build_records.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    # (shape, labels, preds, records, records_bytes, status, stream)
+    lib.dvs_build_records.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
     lib.dvs_loss_forward.restype = c_int
-    lib.dvs_loss_forward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p]
+    # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, eps, status, losses, mu, logvar, stream)
+    lib.dvs_loss_forward.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_loss_backward.restype = c_int
-    lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, gcoef, grads, stream)
+    lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                      c_void_p, c_void_p]
     lib.dvs_encode.restype = c_int
-    lib.dvs_encode.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, mu, logvar, stream)
+    lib.dvs_encode.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p,
+                               c_void_p]
     lib.dvs_decode.restype = c_int
-    lib.dvs_decode.argtypes = [P(DvsShape), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    # (shape, params, n_params, workspace, workspace_bytes, records, records_bytes, z, uniforms, state, state_bytes, stream)
+    lib.dvs_decode.argtypes = [P(DvsShape), c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]
+    lib.dvs_debug_launch.restype = c_int
+    lib.dvs_debug_launch.argtypes = [c_size_t, c_void_p]
     lib.dvs_bic_scores.restype = c_int
     lib.dvs_bic_scores.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]
@@ -64,8 +78,9 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_gp_predict.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, c_void_p, c_void_p]
     lib.dvs_clip_adam.restype = c_int
+    # (n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard, stream)
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
-                                  c_int64, c_float, c_void_p, c_void_p]
+                                  c_int64, c_float, c_void_p, c_void_p, c_void_p]
     lib.dvs_profile_enable.restype = None
     lib.dvs_profile_enable.argtypes = [c_int]
     lib.dvs_profile_collect.restype = c_int
@@ -77,7 +92,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
            "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_gp_predict",
-           "dvs_clip_adam", "dvs_debug_activation", "dvs_profile_enable", "dvs_profile_collect"]
+           "dvs_clip_adam", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
 
 
 def profile_collect(lib):
@@ -109,7 +124,7 @@ def load() -> ctypes.CDLL:
                 f"{LIB_NAME} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(hipcc --offload-arch=gfx950).  dags_vae_search_amd has no CPU fallback.")
         _lib = bind(ctypes.CDLL(path))
-        if _lib.dvs_version() != 100:
+        if _lib.dvs_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_NAME}: unexpected ABI version {_lib.dvs_version()}")
     return _lib
 

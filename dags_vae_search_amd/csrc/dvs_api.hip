@@ -13,6 +13,7 @@ static thread_local char g_err[256] = "";
 
 // ---- optional per-kernel timing (HIP events on the launch stream) -------------------------------------------------
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 namespace {
@@ -22,32 +23,48 @@ struct ProfRec {
     hipEvent_t a, b;
 #endif
 };
+// The one piece of process-global mutable state of the library: begin/end pairs of concurrent callers may interleave
+// (the record then pairs the wrong events), but the container itself is never corrupted.
+std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+thread_local int t_prof_slot = -1;      // index of this thread's open record
 }  // namespace
 
 void dvs_prof_begin(const char* name, dvs_stream_t st) {
+    t_prof_slot = -1;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof_on) return;
     ProfRec r;
     r.name = name;
 #ifndef DVS_EMU
-    (void)hipEventCreate(&r.a);
-    (void)hipEventCreate(&r.b);
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) {
+        (void)hipEventDestroy(r.a);
+        return;
+    }
     (void)hipEventRecord(r.a, st);
 #endif
+    t_prof_slot = (int)g_prof.size();
     g_prof.push_back(r);
 }
 void dvs_prof_end(dvs_stream_t st) {
-    if (!g_prof_on) return;
+    if (t_prof_slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
 #ifndef DVS_EMU
-    (void)hipEventRecord(g_prof.back().b, st);
+    if (t_prof_slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[t_prof_slot].b, st);
 #endif
+    t_prof_slot = -1;
 }
-extern "C" void dvs_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" void dvs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_on = on != 0;
+}
 // Waits for the recorded events, then writes up to `cap` rows (name, launches, total milliseconds); returns the
 // number of distinct kernels and clears the record.
 extern "C" int dvs_profile_collect(char* names, int name_stride, int* counts, float* total_ms, int cap) {
     std::map<std::string, std::pair<int, float>> agg;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) {
         float ms = 0.f;
 #ifndef DVS_EMU
@@ -76,6 +93,32 @@ static int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
 }
+
+// ---- HIP runtime failures inside an entry point (DVS_LAUNCH / DVS_SET_LDS, dvs_kernels.h) ---------------------------
+static thread_local int t_hip_err = 0;
+static thread_local char t_hip_msg[200] = "";
+void dvs_note_hip_error(const char* what, int hip_error, const char* hip_message) {
+    if (t_hip_err != 0) return;             // keep the first failure of the call
+    t_hip_err = hip_error ? hip_error : -1;
+    snprintf(t_hip_msg, sizeof(t_hip_msg), "%s: HIP error %d (%s)", what, hip_error, hip_message ? hip_message : "?");
+}
+static void call_begin() {
+    t_hip_err = 0;
+    (void)hipGetLastError();                // errors that are not ours must not be attributed to our launches
+}
+static int call_end(const char* fn) {
+    if (t_hip_err == 0) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", fn, t_hip_msg);
+    t_hip_err = 0;
+    return 20;
+}
+#ifndef DVS_EMU
+#define DVS_HIP_CALL(expr)                                                             \
+    do {                                                                               \
+        const hipError_t dvs_ce_ = (expr);                                             \
+        if (dvs_ce_ != hipSuccess) dvs_note_hip_error(#expr, (int)dvs_ce_, hipGetErrorString(dvs_ce_)); \
+    } while (0)
+#endif
 
 extern "C" int dvs_version(void) { return DVS_VERSION; }
 extern "C" const char* dvs_last_error(void) { return g_err; }
@@ -228,6 +271,38 @@ static int check_shape(const dvs_shape* s) {
     return 0;
 }
 
+static int64_t param_floats(const dvs_shape* s) { return dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total; }
+int dvs_num_slabs();
+
+// Caller-owned buffers against what the shape needs (include/dvs.h: code 14); nothing has been enqueued yet.
+// Pass a negative / zero "have" for a buffer the entry point does not take.
+static int check_buffers(const dvs_shape* s, const char* fn, bool has_records, size_t records_bytes, bool has_params,
+                         int64_t n_params, bool has_ws, size_t workspace_bytes) {
+    char msg[240];
+    if (has_records) {
+        const size_t need = (size_t)s->batch * ((s->n_tokens > DVS_MAXTOK || s->n_classes > 16) ? sizeof(DvsRecordW) : sizeof(DvsRecord));
+        if (records_bytes < need) {
+            snprintf(msg, sizeof(msg), "%s: records_bytes %zu < batch * dvs_record_bytes = %zu", fn, records_bytes, need);
+            return fail(14, msg);
+        }
+    }
+    if (has_params) {
+        const int64_t need = param_floats(s);
+        if (n_params < need) {
+            snprintf(msg, sizeof(msg), "%s: n_params %lld < dvs_param_count = %lld", fn, (long long)n_params, (long long)need);
+            return fail(14, msg);
+        }
+    }
+    if (has_ws) {
+        const size_t need = dvs_make_workspace(s->batch, (s->n_tokens + 15) / 16, param_floats(s), dvs_num_slabs()).total_floats * sizeof(float);
+        if (workspace_bytes < need) {
+            snprintf(msg, sizeof(msg), "%s: workspace_bytes %zu < dvs_workspace_bytes = %zu", fn, workspace_bytes, need);
+            return fail(14, msg);
+        }
+    }
+    return 0;
+}
+
 // One-tile path: a wave owns a whole DAG (N, C <= 16).  Wide path: NT tiles of 16 tokens per DAG, cross-token kernels
 // of dvs_wide.h (also taken when only the class count exceeds one tile).
 static bool is_wide(const dvs_shape* s) { return s->n_tokens > DVS_MAXTOK || s->n_classes > 16; }
@@ -288,11 +363,13 @@ extern "C" size_t dvs_record_bytes(const dvs_shape* s) {
 }
 
 extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
-                                 const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
-                                 void* stream) {
+                                 const float* adjacency, const uint8_t* target_masks, void* records, size_t records_bytes,
+                                 int32_t* status, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!label_onehot || !pos_onehot || !adjacency || !target_masks || !records || !status)
         return fail(10, "dvs_pack_features: null pointer");
+    if (int e = check_buffers(s, "dvs_pack_features", true, records_bytes, false, 0, false, 0)) return e;
+    call_begin();
     PackArgs a;
     a.B = s->batch;
     a.N = s->n_tokens;
@@ -305,13 +382,15 @@ extern "C" int dvs_pack_features(const dvs_shape* s, const float* label_onehot, 
     a.status = status;
     if (is_wide(s)) dvs_launch_pack_w(a, (dvs_stream_t)stream);
     else dvs_launch_pack(a, (dvs_stream_t)stream);
-    return 0;
+    return call_end("dvs_pack_features");
 }
 
 extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* preds, void* records,
-                                 int32_t* status, void* stream) {
+                                 size_t records_bytes, int32_t* status, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!labels || !preds || !records || !status) return fail(10, "dvs_build_records: null pointer");
+    if (int e = check_buffers(s, "dvs_build_records", true, records_bytes, false, 0, false, 0)) return e;
+    call_begin();
     if (is_wide(s)) {
         BuildWArgs a;
         a.B = s->batch;
@@ -322,7 +401,7 @@ extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, cons
         a.rec = (DvsRecordW*)records;
         a.status = status;
         dvs_launch_build_records_w(a, (dvs_stream_t)stream);
-        return 0;
+        return call_end("dvs_build_records");
     }
     BuildArgs a;
     a.B = s->batch;
@@ -333,7 +412,7 @@ extern "C" int dvs_build_records(const dvs_shape* s, const uint8_t* labels, cons
     a.rec = (DvsRecord*)records;
     a.status = status;
     dvs_launch_build_records(a, (dvs_stream_t)stream);
-    return 0;
+    return call_end("dvs_build_records");
 }
 
 // slot numbering of saved activations
@@ -640,10 +719,13 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
     chain.flush();
 }
 
-extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
-                                const float* eps, float* losses, float* mu, float* logvar, void* stream) {
+extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
+                                int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps,
+                                const int32_t* status, float* losses, float* mu, float* logvar, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
+    if (int e = check_buffers(s, "dvs_loss_forward", true, records_bytes, true, n_params, true, workspace_bytes)) return e;
+    call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
@@ -681,6 +763,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
     fa.B = d.B;
     fa.beta = d.beta;
     fa.dag_loss = ws + W.dag_loss;
+    fa.status = status;
     fa.losses = losses;
     dvs_launch_finalize(fa, st);
     const size_t nb = (size_t)d.B * 32 * sizeof(float);
@@ -688,16 +771,19 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, const f
     if (mu) memcpy(mu, ws + W.mu, nb);
     if (logvar) memcpy(logvar, ws + W.logvar, nb);
 #else
-    if (mu) (void)hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st);
-    if (logvar) (void)hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st);
+    if (mu) DVS_HIP_CALL(hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st));
+    if (logvar) DVS_HIP_CALL(hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st));
 #endif
-    return 0;
+    return call_end("dvs_loss_forward");
 }
 
-extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* params, void* workspace, float* mu,
-                          float* logvar, void* stream) {
+extern "C" int dvs_encode(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
+                          int64_t n_params, void* workspace, size_t workspace_bytes, float* mu, float* logvar,
+                          void* stream) {
     if (int e = check_shape(s)) return e;
     if (!records || !params || !workspace || !mu || !logvar) return fail(10, "dvs_encode: null pointer");
+    if (int e = check_buffers(s, "dvs_encode", true, records_bytes, true, n_params, true, workspace_bytes)) return e;
+    call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
@@ -713,20 +799,25 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, const float* 
     memcpy(mu, ws + W.mu, nb);
     memcpy(logvar, ws + W.logvar, nb);
 #else
-    (void)hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st);
+    DVS_HIP_CALL(hipMemcpyAsync(mu, ws + W.mu, nb, hipMemcpyDeviceToDevice, st));
+    DVS_HIP_CALL(hipMemcpyAsync(logvar, ws + W.logvar, nb, hipMemcpyDeviceToDevice, st));
 #endif
-    return 0;
+    return call_end("dvs_encode");
 }
 
 // ---- generation (k_decode.hip) -------------------------------------------------------------------------------------
 #include "dvs_decode.h"
 
-extern "C" int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* records, const float* z,
-                          const float* uniforms, void* state_out, void* stream) {
+extern "C" int dvs_decode(const dvs_shape* s, const float* params, int64_t n_params, void* workspace,
+                          size_t workspace_bytes, void* records, size_t records_bytes, const float* z,
+                          const float* uniforms, void* state_out, size_t state_bytes, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!params || !workspace || !records || !z || !state_out) return fail(10, "dvs_decode: null pointer");
     if (s->training) return fail(13, "dvs_decode: generation runs in eval mode (shape.training must be 0)");
+    if (int e = check_buffers(s, "dvs_decode", true, records_bytes, true, n_params, true, workspace_bytes)) return e;
+    if (state_bytes < (size_t)s->batch * sizeof(dvs_decode_state))
+        return fail(14, "dvs_decode: state_bytes < batch * sizeof(dvs_decode_state)");
+    call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
@@ -773,7 +864,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, void* workspa
         a.idx = idx;
         dvs_launch_decode_step(a, grid_for(d.B, 4), st);
     }
-    return 0;
+    return call_end("dvs_decode");
 }
 
 extern "C" int dvs_bic_scores_impl(int B, int n, int S, const uint64_t* data, const uint8_t* card, const uint64_t* parents,
@@ -783,7 +874,9 @@ extern "C" int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, 
     if (batch <= 0 || n_samples <= 0) return fail(2, "dvs_bic_scores: batch and n_samples must be > 0");
     if (n_vars < 1 || n_vars > DVS_WTOK) return fail(3, "dvs_bic_scores: n_vars must be in [1, 48]");
     if (!data || !card || !parents || !scratch || !out || !status) return fail(10, "dvs_bic_scores: null pointer");
-    return dvs_bic_scores_impl(batch, n_vars, n_samples, data, card, parents, scratch, out, status, stream);
+    call_begin();
+    if (int e = dvs_bic_scores_impl(batch, n_vars, n_samples, data, card, parents, scratch, out, status, stream)) return e;
+    return call_end("dvs_bic_scores");
 }
 
 extern "C" int dvs_gp_predict_impl(int B, int M, int D, const float* x, const float* z, const double* alpha,
@@ -794,7 +887,9 @@ extern "C" int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, co
     if (batch <= 0 || n_inducing <= 0 || dim <= 0) return fail(2, "dvs_gp_predict: sizes must be > 0");
     if (!(lengthscale > 0.0)) return fail(5, "dvs_gp_predict: lengthscale must be > 0");
     if (!x || !inducing || !alpha || !out) return fail(10, "dvs_gp_predict: null pointer");
-    return dvs_gp_predict_impl(batch, n_inducing, dim, x, inducing, alpha, outputscale, lengthscale, constant, out, stream);
+    call_begin();
+    if (int e = dvs_gp_predict_impl(batch, n_inducing, dim, x, inducing, alpha, outputscale, lengthscale, constant, out, stream)) return e;
+    return call_end("dvs_gp_predict");
 }
 
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
@@ -811,8 +906,20 @@ extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, i
     else if (slot == 104) src = ws + W.gmem;
     else if (slot == 105) src = ws + W.genc;
     else return fail(11, "dvs_debug_activation: bad slot");
+    call_begin();
     dvs_launch_unfrag(src, out, s->batch * tiles_of(s), (dvs_stream_t)stream);
-    return 0;
+    return call_end("dvs_debug_activation");
+}
+
+// Error-path test hook (include/dvs.h): an empty kernel through the product's launch macro.
+__global__ void k_debug_empty(int* sink) {
+    DVS_DYN_LDS(smem);
+    if (sink && threadIdx.x == 1u << 20) *sink = smem[0];
+}
+extern "C" int dvs_debug_launch(size_t dynamic_lds_bytes, void* stream) {
+    call_begin();
+    DVS_LAUNCH(k_debug_empty, dim3(1), dim3(64), dynamic_lds_bytes, (dvs_stream_t)stream, (int*)nullptr);
+    return call_end("dvs_debug_launch");
 }
 
 #include "dvs_api_backward.inc"

@@ -112,7 +112,7 @@ void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st);
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st);
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st);
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
-                          float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st);
+                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, dvs_stream_t st);
 size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave);
 
 // ---- slab reduction helpers ---------------------------------------------------------------------------------------

@@ -96,7 +96,8 @@ struct FinalizeArgs {
     int B;
     float beta;
     const float* dag_loss;
-    float* losses;               // [4]
+    const int* status;           // optional validation word of the pack / build call
+    float* losses;               // [DVS_LOSS_FLOATS]
 };
 
 struct BuildArgs {
@@ -136,24 +137,36 @@ void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st);
 // dvs_profile_enable(1) ... launches ... dvs_profile_collect(): see include/dvs.h.
 void dvs_prof_begin(const char* name, dvs_stream_t st);
 void dvs_prof_end(dvs_stream_t st);
-#define DVS_LAUNCH(kernel, grid, block, lds, st, ...)                      \
-    do {                                                                   \
-        dvs_prof_begin(#kernel, st);                                       \
-        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);     \
-        dvs_prof_end(st);                                                  \
+// A launch the runtime refuses (dynamic-LDS request above the limit, bad grid, ...) must not look like success: the
+// first failure inside one entry-point call is kept per thread (dvs_note_hip_error) and becomes that call's return code
+// and dvs_last_error() message (dvs_api.hip: call_begin / call_end).
+void dvs_note_hip_error(const char* what, int hip_error, const char* hip_message);
+#define DVS_LAUNCH(kernel, grid, block, lds, st, ...)                                          \
+    do {                                                                                       \
+        dvs_prof_begin(#kernel, st);                                                           \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                         \
+        const hipError_t dvs_le_ = hipGetLastError();                                          \
+        if (dvs_le_ != hipSuccess) dvs_note_hip_error(#kernel, (int)dvs_le_, hipGetErrorString(dvs_le_)); \
+        dvs_prof_end(st);                                                                      \
     } while (0)
 
 #ifndef DVS_EMU
 // Raise a kernel's dynamic-LDS limit once per (call site, device): hipFuncSetAttribute costs several microseconds of
 // host time, which shows up as GPU idle at the start of every step (the host is not yet ahead of the device there).
+// A refused request is recorded like a refused launch and is NOT cached, so the next call reports it again.
 #define DVS_SET_LDS(kernel, bytes)                                                                                   \
     do {                                                                                                             \
         static size_t dvs_lds_set_[16] = {0};                                                                        \
         int dvs_dev_ = 0;                                                                                            \
-        (void)hipGetDevice(&dvs_dev_);                                                                               \
+        if (hipGetDevice(&dvs_dev_) != hipSuccess) dvs_dev_ = -1;                                                    \
         if (dvs_dev_ < 0 || dvs_dev_ >= 16 || dvs_lds_set_[dvs_dev_] < (size_t)(bytes)) {                            \
-            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-            if (dvs_dev_ >= 0 && dvs_dev_ < 16) dvs_lds_set_[dvs_dev_] = (size_t)(bytes);                            \
+            const hipError_t dvs_ae_ = hipFuncSetAttribute((const void*)kernel,                                      \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (dvs_ae_ != hipSuccess)                                                                               \
+                dvs_note_hip_error("hipFuncSetAttribute(" #kernel ", max dynamic LDS)", (int)dvs_ae_,               \
+                                   hipGetErrorString(dvs_ae_));                                                      \
+            else if (dvs_dev_ >= 0 && dvs_dev_ < 16)                                                                 \
+                dvs_lds_set_[dvs_dev_] = (size_t)(bytes);                                                            \
         }                                                                                                            \
     } while (0)
 #else

@@ -256,7 +256,7 @@ void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 // Deterministic reduction of the per-DAG losses: recon = sum NLL, kld = sum KL, total = recon + beta * kld
 // (pace.py:2030-2035).  losses[3] = 1 if anything is non-finite (replaces the per-layer isnan host sync,
-// pace.py:97-98, by one device-side flag per step).
+// pace.py:97-98, by one device-side flag per step); losses[4] = 1 if the records' validation word is set.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
     __shared__ float s0[256], s1[256];
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
         a.losses[1] = recon;
         a.losses[2] = kld;
         a.losses[3] = (total - total == 0.f) ? 0.f : 1.f;
+        a.losses[4] = (a.status && *a.status != 0) ? 1.f : 0.f;      // invalid-features flag (travels with the scalars)
     }
 }
 

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_part(const float* g, int64_t n, 
 // Every workgroup of k_adam re-derives the clip coefficient from the 256 partials (same tree, same order: bitwise the same
 // value everywhere) instead of waiting for a one-workgroup launch in between; workgroup 0 publishes it.
 __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt, float max_norm, float* scratch) {
+                                              float eps, float bc1, float bc2_sqrt, float max_norm, float* scratch,
+                                              const float* guard) {
     __shared__ float part[256];
     part[threadIdx.x] = scratch[2 + threadIdx.x];
     __syncthreads();
@@ -44,6 +45,9 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
         scratch[0] = ss;
         scratch[1] = coef;
     }
+    // non-finite loss or invalid features: the reference raises inside loss_direct, before backward / clip / step, so
+    // neither the weights nor the moments move (uniform branch: every thread reads the same two words)
+    if (guard && (guard[0] != 0.f || guard[1] != 0.f)) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i] * coef;
@@ -57,12 +61,12 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
 }
 
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
-                          float eps, int64_t step, float max_norm, float* scratch, dvs_stream_t st) {
+                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, dvs_stream_t st) {
     DVS_LAUNCH(k_sqnorm_part, dim3(SQ_PARTS), dim3(256), 0, st, (const float*)grads, n, scratch);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
     DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
-                       bc1, sqrtf(bc2), max_norm, scratch);
+                       bc1, sqrtf(bc2), max_norm, scratch, guard);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -17,6 +17,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _nbytes(t: torch.Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -109,7 +113,8 @@ class PaceEngine:
             self._status.zero_()
         shape = self.shape(B)
         dl.check(self.lib, self.lib.dvs_pack_features(ctypes.byref(shape), _ptr(lab), _ptr(pos), _ptr(adj), _ptr(tm),
-                                                      _ptr(self._records), _ptr(self._status), _stream()),
+                                                      _ptr(self._records), _nbytes(self._records), _ptr(self._status),
+                                                      _stream()),
                  "dvs_pack_features")
         if check:
             st = self._read_status()
@@ -134,7 +139,8 @@ class PaceEngine:
             self._status.zero_()
         shape = self.shape(B)
         dl.check(self.lib, self.lib.dvs_build_records(ctypes.byref(shape), _ptr(labels), _ptr(preds), _ptr(self._records),
-                                                      _ptr(self._status), _stream()), "dvs_build_records")
+                                                      _nbytes(self._records), _ptr(self._status), _stream()),
+                 "dvs_build_records")
         if check:
             st = self._read_status()
             if st:
@@ -146,19 +152,26 @@ class PaceEngine:
                      mu: Optional[torch.Tensor] = None, logvar: Optional[torch.Tensor] = None):
         _require_cuda(params, "parameters")
         ws = self.workspace(shape.batch, params.device)
-        dl.check(self.lib, self.lib.dvs_loss_forward(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
-                                                     _ptr(eps), _ptr(losses), _ptr(mu), _ptr(logvar), _stream()),
+        if losses.numel() < dl.LOSS_FLOATS:
+            raise ValueError(f"losses must hold {dl.LOSS_FLOATS} floats")
+        dl.check(self.lib, self.lib.dvs_loss_forward(ctypes.byref(shape), _ptr(self._records), _nbytes(self._records),
+                                                     _ptr(params), params.numel(), _ptr(ws), _nbytes(ws), _ptr(eps),
+                                                     _ptr(self._status), _ptr(losses), _ptr(mu), _ptr(logvar), _stream()),
                  "dvs_loss_forward")
 
     def loss_backward(self, shape, params: torch.Tensor, gcoef: torch.Tensor, grads: torch.Tensor):
         ws = self.workspace(shape.batch, params.device)
-        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
-                                                      _ptr(gcoef), _ptr(grads), _stream()), "dvs_loss_backward")
+        if grads.numel() < params.numel():
+            raise ValueError("gradient buffer is smaller than the parameter buffer")
+        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(shape), _ptr(self._records), _nbytes(self._records),
+                                                      _ptr(params), params.numel(), _ptr(ws), _nbytes(ws), _ptr(gcoef),
+                                                      _ptr(grads), _stream()), "dvs_loss_backward")
 
     def encode(self, shape, params: torch.Tensor, mu: torch.Tensor, logvar: torch.Tensor):
         ws = self.workspace(shape.batch, params.device)
-        dl.check(self.lib, self.lib.dvs_encode(ctypes.byref(shape), _ptr(self._records), _ptr(params), _ptr(ws),
-                                               _ptr(mu), _ptr(logvar), _stream()), "dvs_encode")
+        dl.check(self.lib, self.lib.dvs_encode(ctypes.byref(shape), _ptr(self._records), _nbytes(self._records),
+                                               _ptr(params), params.numel(), _ptr(ws), _nbytes(ws), _ptr(mu), _ptr(logvar),
+                                               _stream()), "dvs_encode")
 
     def decode(self, shape, params: torch.Tensor, z: torch.Tensor, uniforms: Optional[torch.Tensor]) -> torch.Tensor:
         """dvs_decode: the whole autoregressive generation loop on the device.  Returns the raw dvs_decode_state
@@ -168,14 +181,17 @@ class PaceEngine:
         B = z.shape[0]
         ws = self.workspace(B, params.device)
         state = torch.empty(B, dl.DECODE_STATE_BYTES, dtype=torch.uint8, device=params.device)
-        dl.check(self.lib, self.lib.dvs_decode(ctypes.byref(shape), _ptr(params), _ptr(ws), _ptr(self._records), _ptr(z),
-                                               _ptr(uniforms), _ptr(state), _stream()), "dvs_decode")
+        dl.check(self.lib, self.lib.dvs_decode(ctypes.byref(shape), _ptr(params), params.numel(), _ptr(ws), _nbytes(ws),
+                                               _ptr(self._records), _nbytes(self._records), _ptr(z), _ptr(uniforms),
+                                               _ptr(state), _nbytes(state), _stream()), "dvs_decode")
         return state
 
-    def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch):
+    def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard=None):
+        """guard: optional device f32[2] = [non-finite flag, invalid-features flag]; the update is skipped on the device
+        when either is non-zero (include/dvs.h)."""
         dl.check(self.lib, self.lib.dvs_clip_adam(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg),
                                                   _ptr(exp_avg_sq), lr, beta1, beta2, eps, int(step), float(max_norm),
-                                                  _ptr(scratch), _stream()), "dvs_clip_adam")
+                                                  _ptr(scratch), _ptr(guard), _stream()), "dvs_clip_adam")
 
     def activation(self, batch: int, slot: int) -> torch.Tensor:
         out = torch.empty(batch, 16 * self.tiles, 64, dtype=torch.float32, device=self._ws.device)

@@ -78,7 +78,7 @@ class _PaceLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, shape, eps, *params):
-        losses = torch.zeros(4, dtype=torch.float32, device=model.flat_params.device)
+        losses = torch.zeros(dl.LOSS_FLOATS, dtype=torch.float32, device=model.flat_params.device)
         model._engine.loss_forward(shape, model.flat_params, eps, losses)
         model._fwd_generation += 1
         ctx.model, ctx.shape, ctx.generation = model, shape, model._fwd_generation
@@ -247,14 +247,17 @@ class PaceVaeV3(nn.Module):
         are: the check looks at the first and last parameter, which is what zero_grad(set_to_none=True) of a stock
         optimiser would have cleared)."""
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
-            # gradient buffer + 4 loss scalars in ONE allocation: the data-parallel step all-reduces both in one call
-            # ... followed by the int32 feature-validation word, so that ONE small device->host copy ends a train step
+            # gradient buffer + the 5 step scalars [total, recon, kld, non-finite flag, invalid-features flag] in ONE
+            # allocation: the data-parallel step all-reduces both in one call (the two flags travel with the losses, so every
+            # rank skips the same update and raises the same error) ... followed by the rank-local int32 feature-validation
+            # word (last word of the tail), so that ONE small device->host copy ends a train step
             P = self.flat_params.numel()
             self._grads_and_losses = torch.zeros(P + 8, dtype=torch.float32, device=self.flat_params.device)
             self.flat_grads = self._grads_and_losses[:P]
-            self._step_losses = self._grads_and_losses[P:P + 4]
+            self._step_losses = self._grads_and_losses[P:P + dl.LOSS_FLOATS]
+            self._step_guard = self._grads_and_losses[P + 3:P + 5]      # dvs_clip_adam skips the update when either is set
             self._step_tail = self._grads_and_losses[P:P + 8]
-            self._step_status = self._grads_and_losses[P + 4:P + 5].view(torch.int32)
+            self._step_status = self._grads_and_losses[P + 7:P + 8].view(torch.int32)
             self._host_tail = torch.zeros(8, dtype=torch.float32)
             if self.flat_params.is_cuda:
                 self._host_tail = self._host_tail.pin_memory()
@@ -332,10 +335,10 @@ class PaceVaeV3(nn.Module):
 
     def read_step(self):
         """The one host synchronisation of a fused train step: a pinned device->host copy of [total, recon, kld,
-        non-finite flag, validation bits]; the validation word is re-armed behind the copy.  After ``_early_read`` the
+        non-finite flag, invalid-features flag, -, -, validation bits]; the validation word is re-armed behind the copy.  After ``_early_read`` the
         copy is already in flight on the side stream (wait for its event); otherwise it is issued here, at the end of the
         step (data-parallel steps: the loss scalars are only global after the all-reduce).
-        Returns (losses list of 4 floats, status int)."""
+        Returns (list of 5 floats, rank-local status bits)."""
         if self._early_pending:
             self._early_pending = False
             self._ev_tail.synchronize()
@@ -344,8 +347,8 @@ class PaceVaeV3(nn.Module):
             self._step_status.zero_()
             torch.cuda.current_stream().synchronize()
         vals = self._host_tail.tolist()
-        status = int(self._host_tail.view(torch.int32)[4])
-        return vals[:4], status
+        status = int(self._host_tail.view(torch.int32)[7])
+        return vals[:5], status
 
     def _shape(self, batch: int, beta: float):
         return self._eng().shape(batch, training=self.training, dropout=self.dropout, beta=beta, eps_scale=0.01,
@@ -443,7 +446,7 @@ class PaceVaeV3(nn.Module):
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
                       packed: bool = False, defer_check: bool = False, early_read: bool = False) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
-        [total, recon, kld, non-finite flag]; nothing is synchronised."""
+        [total, recon, kld, non-finite flag, invalid-features flag]; nothing is synchronised."""
         eng = self._eng()
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
             self.bind_flat_grads()        # first step: allocate (also hands the validation word to the engine)

@@ -51,16 +51,23 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
         if group is not None:
             from .dist import allreduce_gradients
             allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
-        optimizer.step(max_grad_norm=max_grad_norm)
+        # A non-finite loss or an invalid batch must leave the weights and the moments alone: the reference raises inside
+        # loss_direct (pace.py:97-98), before backward / clip / step (main.py:111-116).  The optimiser kernels are already
+        # enqueued when the host learns about it, so they carry the two flags as a device-side guard and skip the update
+        # (data-parallel: the flags were all-reduced with the losses, every rank skips and raises alike).
+        optimizer.step(max_grad_norm=max_grad_norm, guard=model._step_guard)
         early = group is None
         scalars = None if early else losses.clone()                 # `losses` is a reused device buffer
         host, status = model.read_step()                            # the step's only host sync (one 32-byte copy)
         if early:
             scalars = model._early_scalars                          # cloned behind the forward on the side stream
         recon, kld = scalars[1], scalars[2]
-        if status != 0:
-            raise ValueError(f"batch violates the feature invariants (status bits {status:#x})")
+        if status != 0 or host[4] != 0.0:
+            optimizer.step_skipped()
+            raise ValueError(f"batch violates the feature invariants (status bits {status:#x}"
+                             f"{'' if status else ', raised on another rank'})")
         if host[3] != 0.0:
+            optimizer.step_skipped()
             raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
         return host[0], recon, kld
     loss, recon, kld = model.loss_direct(batch)

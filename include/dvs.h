@@ -9,8 +9,13 @@
  * Conventions: plain pointers and sizes only (no torch types).  Every pointer marked "device" is device
  * memory owned by the caller; the library never allocates or frees device memory and never synchronises
  * the host with the device.  All work is enqueued on the passed HIP stream (void* = hipStream_t).
- * Return value: 0 = ok, non-zero = error code; dvs_last_error() gives the thread-local message.
- * Entry points are re-entrant (no global mutable state).
+ * Return value: 0 = ok, non-zero = error code; dvs_last_error() gives the thread-local message.  Codes: 1-5 bad shape,
+ * 10 null pointer, 12/13 bad argument, 14 a caller buffer is smaller than the shape needs (records_bytes, n_params,
+ * workspace_bytes, state_bytes are checked against dvs_record_bytes / dvs_param_count / dvs_workspace_bytes BEFORE anything
+ * is enqueued), 20 the HIP runtime refused a kernel launch or an attribute/copy call of this entry point (message names
+ * the kernel and carries hipGetErrorString; work enqueued before the failing launch stays enqueued, results are undefined).
+ * Entry points are re-entrant: the only process-global state is the optional profiler record (dvs_profile_*), which is
+ * mutex-guarded; error state is thread-local.
  *
  * Fixed architecture of this build (BASELINE.json configs; experiments/01_bn_asia/main.py:33-43):
  * vertices_embedding_size 32, num_heads 8, num_layers 3, ff_hidden_size 64, latent_layer_size 32,
@@ -28,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DVS_VERSION 100
+#define DVS_VERSION 200
 #define DVS_NUM_PARAMS 108
 #define DVS_RECORD_BYTES 96          /* one-tile path */
 #define DVS_RECORD_BYTES_WIDE 864    /* wide path; dvs_record_bytes(shape) returns the one that applies */
@@ -74,8 +79,8 @@ size_t dvs_record_bytes(const dvs_shape* s);
  * (dvs_record_bytes) per DAG.  status (device int32[1], zeroed by the caller) gets bit 0 set if a label/position
  * row is not one-hot, bit 1 if the 8 per-head masks of a DAG differ, bit 2 if a mask row forbids self. */
 int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float* pos_onehot,
-                      const float* adjacency, const uint8_t* target_masks, void* records, int32_t* status,
-                      void* stream);
+                      const float* adjacency, const uint8_t* target_masks, void* records, size_t records_bytes,
+                      int32_t* status, void* stream);
 
 /* Device-side feature front-end (replaces LabeledDag.from_dict_to_graph src/toolkit/labeled.py:132-154 +
  * from_labeled_graph_to_pace_graph pace.py:1250-1288 + generate_mask 1307-1343 + prepare_features 1345-1478 + pack):
@@ -83,32 +88,44 @@ int dvs_pack_features(const dvs_shape* s, const float* label_onehot, const float
  * preds: device [B][n], bit u of preds[b][v] set <=> edge u -> v (the e{v} '0/1' string, u < v); element type u16 on
  * the one-tile path (dvs_record_bytes == 96), u64 on the wide path.  One thread per DAG does the PACE wrapping, the
  * FIFO-Kahn topological order (positions[v] = order[v], the reference's quirk), and the ancestor closure on bit rows.  status bit 0: a label is >= n_classes - 3; bit 3: an edge with u >= v. */
-int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* preds, void* records, int32_t* status,
-                      void* stream);
+int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* preds, void* records, size_t records_bytes,
+                      int32_t* status, void* stream);
+
+/* Buffer sizes: every compute entry point takes the byte size of the record buffer (>= batch * dvs_record_bytes), the
+ * float count of the flat parameter (and gradient) buffer (>= dvs_param_count) and the byte size of the workspace
+ * (>= dvs_workspace_bytes) and returns 14 without enqueueing anything when one is too small. */
 
 /* PaceVaeV3.loss_direct forward (pace.py:1974-2035).  eps: optional device [B,32] noise already multiplied
- * by eps_scale (NULL = counter-based normal draws when training).  losses (device f32[4]):
- * {total, recon = -log-likelihood, kld, non-finite flag}.  mu/logvar: optional device [B,32] outputs. */
-int dvs_loss_forward(const dvs_shape* s, const void* records, const float* params, void* workspace,
-                     const float* eps, float* losses, float* mu, float* logvar, void* stream);
+ * by eps_scale (NULL = counter-based normal draws when training).  losses (device f32[DVS_LOSS_FLOATS = 5]):
+ * {total, recon = -log-likelihood, kld, non-finite flag, invalid-features flag}.  status: optional device int32[1], the
+ * validation word of the dvs_pack_features / dvs_build_records call that wrote `records`; losses[4] = 1 if it is
+ * non-zero (0 when status is NULL), so that the flag can travel with the loss scalars (data-parallel all-reduce,
+ * dvs_clip_adam's guard).  mu/logvar: optional device [B,32] outputs. */
+#define DVS_LOSS_FLOATS 5
+int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
+                     void* workspace, size_t workspace_bytes, const float* eps, const int32_t* status, float* losses,
+                     float* mu, float* logvar, void* stream);
 
 /* Backward of the same step (autograd of pace.py:1974-2035; experiments/03_synthetic_12/main.py:114).  Must follow
  * dvs_loss_forward on the same workspace and parameters: it reads the forward's saved activations and per-step weight images.
  * gcoef (device f32[2]): d(objective)/d(recon), d(objective)/d(kld).  grads: flat buffer, overwritten. */
-int dvs_loss_backward(const dvs_shape* s, const void* records, const float* params, void* workspace,
-                      const float* gcoef, float* grads, void* stream);
+int dvs_loss_backward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
+                      void* workspace, size_t workspace_bytes, const float* gcoef, float* grads, void* stream);
 
 /* PaceVaeV3.encode_direct (pace.py:1613-1641): mu, logvar device [B,32]. */
-int dvs_encode(const dvs_shape* s, const void* records, const float* params, void* workspace, float* mu,
-               float* logvar, void* stream);
+int dvs_encode(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
+               void* workspace, size_t workspace_bytes, float* mu, float* logvar, void* stream);
 
 /* clip_grad_norm_(params, max_norm) + Adam.step (experiments/03_synthetic_12/main.py:115-116, lr 1e-4,
  * betas (0.9, 0.999), eps 1e-8, no weight decay) over flat buffers of n floats.  max_norm <= 0 disables
  * clipping.  scratch: device f32[DVS_CLIP_SCRATCH_FLOATS] ([0] = sum of squares, [1] = clip coefficient, rest =
- * partial sums); `step` is the 1-based Adam step. */
+ * partial sums); `step` is the 1-based Adam step.  guard: optional device f32[2] (normally &losses[3] of the step's
+ * dvs_loss_forward, after the data-parallel all-reduce): when guard[0] != 0 (non-finite loss) or guard[1] != 0 (invalid
+ * features) the whole update is skipped on the device — params, exp_avg, exp_avg_sq and grads stay as they are, as in the
+ * reference, where loss_direct raises before backward / clip / step run (pace.py:97-98, main.py:111-116). */
 int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
-                  void* stream);
+                  const float* guard, void* stream);
 
 /* One grown PACE graph of dvs_decode (vertex 0 = start, 1 = input, then the sampled vertices in order). */
 typedef struct dvs_decode_state {
@@ -125,8 +142,9 @@ typedef struct dvs_decode_state {
  * f32 [B, n_tokens, n_tokens]; step idx uses [b, idx, 0] for the node type (inverse CDF, as np.random.choice) and
  * [b, idx, 1 + vi] for edge candidate vi (edge iff u < sigmoid score, as torch.rand_like < score); NULL = counter-based
  * draws from s->seed.  s->training must be 0 (the reference decodes in eval mode). */
-int dvs_decode(const dvs_shape* s, const float* params, void* workspace, void* records, const float* z,
-               const float* uniforms, void* state_out, void* stream);
+int dvs_decode(const dvs_shape* s, const float* params, int64_t n_params, void* workspace, size_t workspace_bytes,
+               void* records, size_t records_bytes, const float* z, const float* uniforms, void* state_out,
+               size_t state_bytes, void* stream);
 
 /* BIC of B discrete Bayesian-network structures on one data set (replaces BNLearnWrapper.score,
  * src/problem/bn/bnlearn.py:27-61 = `Rscript bnlearn_score.R`: bnlearn::score(net, data, type = "bic")).
@@ -155,6 +173,10 @@ int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, const float* 
  * debug state; leave disabled in production. */
 void dvs_profile_enable(int on);
 int dvs_profile_collect(char* names, int name_stride, int* counts, float* total_ms, int cap);
+
+/* Test hook for the error path: launches an empty kernel with `dynamic_lds_bytes` of dynamic LDS through the same launch
+ * macro as every product kernel.  A request above the 160 KB of a gfx950 CU must come back as code 20. */
+int dvs_debug_launch(size_t dynamic_lds_bytes, void* stream);
 
 /* Debug/test access: copy saved activation `slot` (natural [B, 16*ceil(n_tokens/16), 64] layout) out of the workspace. */
 int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream);

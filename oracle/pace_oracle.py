@@ -205,52 +205,60 @@ def _seq_mask(masks, site, x_lbd):
     return torch.from_numpy(masks.tile(site, B, L, d)).transpose(0, 1)
 
 
-def _ffn(P, prefix, cfg, x, training, masks=None, site=0):
-    h = torch.relu(F.linear(x, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
+def _relu(hook, name, pre):
+    """ReLU of a hidden layer.  `hook` (tests only, tests/relu_trace.py) sees the pre-activation under the layer's
+    state-dict prefix and may evaluate the network on a prescribed linear piece (pre * mask) instead: the parity tests
+    use it to count sign disagreements with the device at near-zero pre-activations and to compare gradients on the
+    SAME piece of this piecewise-linear function."""
+    return torch.relu(pre) if hook is None else hook(name, pre)
+
+
+def _ffn(P, prefix, cfg, x, training, masks=None, site=0, relu=None):
+    h = _relu(relu, prefix + ".linear1", F.linear(x, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
     h = _drop(h, cfg.dropout, training, _seq_mask(masks, site, h))
     return F.linear(h, P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"])
 
 
-def _encoder(P, cfg, x, mask, training, masks=None):
+def _encoder(P, cfg, x, mask, training, masks=None, relu=None):
     for l in range(cfg.layers):
         pre = f"encoder.layers.{l}"
         a = _mha(P, pre + ".self_attn", cfg, x, x, mask, training, masks, site_enc(l, 0))
         x = _ln(P, pre + ".norm1", x + _drop(a, cfg.dropout, training, _seq_mask(masks, site_enc(l, 1), a)))
-        f = _ffn(P, pre, cfg, x, training, masks, site_enc(l, 2))
+        f = _ffn(P, pre, cfg, x, training, masks, site_enc(l, 2), relu)
         x = _ln(P, pre + ".norm2", x + _drop(f, cfg.dropout, training, _seq_mask(masks, site_enc(l, 3), f)))
         if torch.isnan(x).any():  # pace.py:97-98
             raise ValueError(f"NaN detected in the output of encoder layer {l}")
     return x
 
 
-def _decoder(P, cfg, t, memory, mask, training, masks=None):
+def _decoder(P, cfg, t, memory, mask, training, masks=None, relu=None):
     for l in range(cfg.layers):
         pre = f"decoder.layers.{l}"
         a = _mha(P, pre + ".self_attn", cfg, t, t, mask, training, masks, site_dec(l, 0))
         t = _ln(P, pre + ".norm1", t + _drop(a, cfg.dropout, training, _seq_mask(masks, site_dec(l, 1), a)))
         a = _mha(P, pre + ".multihead_attn", cfg, t, memory, mask, training, masks, site_dec(l, 2))   # tgt_mask, pace.py:148
         t = _ln(P, pre + ".norm2", t + _drop(a, cfg.dropout, training, _seq_mask(masks, site_dec(l, 3), a)))
-        f = _ffn(P, pre, cfg, t, training, masks, site_dec(l, 4))
+        f = _ffn(P, pre, cfg, t, training, masks, site_dec(l, 4), relu)
         t = _ln(P, pre + ".norm3", t + _drop(f, cfg.dropout, training, _seq_mask(masks, site_dec(l, 5), f)))
     return t
 
 
-def encode_direct(P, cfg: PaceConfig, features: Dict, training: bool = False, masks=None):
+def encode_direct(P, cfg: PaceConfig, features: Dict, training: bool = False, masks=None, relu=None):
     """pace.py:1613-1641 -> (mu, logvar) [B, latent]."""
     x = _embed(P, cfg, features["vertex_label_features"], features["vertex_position_features"],
                features["adjacency_matrices"], training, masks, 0)
-    mem = _encoder(P, cfg, x.transpose(0, 1), features["target_masks"], training, masks)
+    mem = _encoder(P, cfg, x.transpose(0, 1), features["target_masks"], training, masks, relu)
     flat = mem.transpose(0, 1).reshape(-1, cfg.N * cfg.d_model)
     return (F.linear(flat, P["fc1.weight"], P["fc1.bias"]),
             F.linear(flat, P["fc2.weight"], P["fc2.bias"]))
 
 
-def log_likelihood(P, cfg: PaceConfig, features: Dict, dec_out: torch.Tensor) -> torch.Tensor:
+def log_likelihood(P, cfg: PaceConfig, features: Dict, dec_out: torch.Tensor, relu=None) -> torch.Tensor:
     """pace.py:1880-1972: node log-softmax gather (target = label of the NEXT vertex, positions
     0..N-2) + edge BCE over all pairs j < i <= N-2 with truth adj[b, j+1, i+1]."""
     B, N = dec_out.shape[0], cfg.N
     adj = features["adjacency_matrices"]
-    h = torch.relu(F.linear(dec_out, P["add_node.0.weight"], P["add_node.0.bias"]))
+    h = _relu(relu, "add_node.0", F.linear(dec_out, P["add_node.0.weight"], P["add_node.0.bias"]))
     logp = torch.log_softmax(F.linear(h, P["add_node.2.weight"], P["add_node.2.bias"]), dim=2)
     tgt = torch.zeros(B, N, dtype=torch.long)
     vl = torch.tensor([list(v)[:N] for v in features["vertex_labels"]], dtype=torch.long)
@@ -267,18 +275,20 @@ def log_likelihood(P, cfg: PaceConfig, features: Dict, dec_out: torch.Tensor) ->
     i_idx = ii.unsqueeze(0).expand(B, -1, -1)[keep]
     j_idx = jj.unsqueeze(0).expand(B, -1, -1)[keep]
     pair = torch.cat([dec_out[b_idx, i_idx], dec_out[b_idx, j_idx]], dim=1)
-    e = torch.relu(F.linear(pair, P["add_edge.0.weight"], P["add_edge.0.bias"]))
+    if relu is not None and hasattr(relu, "aux"):
+        relu.aux["pairs"] = (b_idx, i_idx, j_idx)
+    e = _relu(relu, "add_edge.0", F.linear(pair, P["add_edge.0.weight"], P["add_edge.0.bias"]))
     logit = F.linear(e, P["add_edge.2.weight"], P["add_edge.2.bias"])
     truth = adj[b_idx, j_idx + 1, i_idx + 1].view(-1, 1)
     return ll - F.binary_cross_entropy_with_logits(logit, truth, reduction="sum")
 
 
 def loss_direct(P, cfg: PaceConfig, features: Dict, beta: float = 0.005, training: bool = False,
-                eps: Optional[torch.Tensor] = None, return_aux: bool = False, masks=None):
+                eps: Optional[torch.Tensor] = None, return_aux: bool = False, masks=None, relu=None):
     """pace.py:1974-2035 -> (total, recon, kld).  ``eps`` (already scaled by epsilon_scale=0.01)
     replaces the reference's ``randn_like(std) * 0.01`` draw when given (train mode only).  ``masks``
     (oracle.rng.DeviceMasks) injects the device's dropout masks instead of torch's own draws."""
-    mu, logvar = encode_direct(P, cfg, features, training, masks)
+    mu, logvar = encode_direct(P, cfg, features, training, masks, relu)
     if training:
         std = torch.exp(0.5 * logvar)
         if eps is None:
@@ -289,8 +299,8 @@ def loss_direct(P, cfg: PaceConfig, features: Dict, beta: float = 0.005, trainin
     mem = F.linear(z, P["fc3.weight"], P["fc3.bias"]).reshape(-1, cfg.N, cfg.d_model).transpose(0, 1)
     x = _embed(P, cfg, features["vertex_label_features"], features["vertex_position_features"],
                features["adjacency_matrices"], training, masks, 2)
-    dec = _decoder(P, cfg, x.transpose(0, 1), mem, features["target_masks"], training, masks).transpose(0, 1)
-    ll = log_likelihood(P, cfg, features, dec)
+    dec = _decoder(P, cfg, x.transpose(0, 1), mem, features["target_masks"], training, masks, relu).transpose(0, 1)
+    ll = log_likelihood(P, cfg, features, dec, relu)
     kld = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
     total = -ll + beta * kld
     if return_aux:

@@ -44,23 +44,27 @@ class EmuModel:
         tm = np.ascontiguousarray(feats["target_masks"]).astype(np.uint8)
         status = np.zeros(1, np.int32)
         dl.check(self.lib, self.lib.dvs_pack_features(ctypes.byref(self.shape), ptr(lab), ptr(pos), ptr(adj), ptr(tm),
-                                                      ptr(self.records), ptr(status), None), "pack")
+                                                      ptr(self.records), self.records.nbytes, ptr(status), None), "pack")
+        self.status = status
         return int(status[0])
 
     def forward(self, eps=None):
-        losses = np.zeros(4, np.float32)
+        losses = np.zeros(dl.LOSS_FLOATS, np.float32)
         mu = np.zeros((self.batch, 32), np.float32)
         lv = np.zeros((self.batch, 32), np.float32)
         e = None if eps is None else np.ascontiguousarray(eps, np.float32)
-        dl.check(self.lib, self.lib.dvs_loss_forward(ctypes.byref(self.shape), ptr(self.records), ptr(self.flat),
-                                                     ptr(self.ws), ptr(e), ptr(losses), ptr(mu), ptr(lv), None), "forward")
+        dl.check(self.lib, self.lib.dvs_loss_forward(ctypes.byref(self.shape), ptr(self.records), self.records.nbytes,
+                                                     ptr(self.flat), self.flat.size, ptr(self.ws), self.ws.nbytes, ptr(e),
+                                                     ptr(getattr(self, "status", None)), ptr(losses), ptr(mu), ptr(lv),
+                                                     None), "forward")
         return losses, mu, lv
 
     def backward(self, g_recon=1.0, g_kld=0.005):
         gcoef = np.asarray([g_recon, g_kld], np.float32)
         grads = np.full(self.P, np.nan, np.float32)
-        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(self.shape), ptr(self.records), ptr(self.flat),
-                                                      ptr(self.ws), ptr(gcoef), ptr(grads), None), "backward")
+        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(self.shape), ptr(self.records), self.records.nbytes,
+                                                      ptr(self.flat), self.flat.size, ptr(self.ws), self.ws.nbytes,
+                                                      ptr(gcoef), ptr(grads), None), "backward")
         return {name: grads[off:off + int(np.prod(shp))].reshape(shp) for name, off, shp in self.table}, grads
 
     def activation(self, slot):

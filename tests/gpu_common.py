@@ -17,7 +17,7 @@ def gpu_forward(cfg, params, graphs, training=False, dropout=0.15, eps=None, see
     flat = eng.flatten(params, dev)
     B = len(graphs)
     shape = eng.shape(B, training=training, dropout=dropout, seed=seed)
-    losses = torch.zeros(4, device=dev)
+    losses = torch.zeros(5, device=dev)
     mu = torch.zeros(B, 32, device=dev)
     lv = torch.zeros(B, 32, device=dev)
     e = None if eps is None else torch.as_tensor(eps, dtype=torch.float32, device=dev).contiguous()

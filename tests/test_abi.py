@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_queries_without_a_gpu():
     lib = dl.load()
-    assert lib.dvs_version() == 100
+    assert lib.dvs_version() == 200 == dl.ABI_VERSION
     shape = dl.make_shape(4096, 15, 15)
     table, total = dl.param_table(lib, shape)
     assert len(table) == 108 and total % 4 == 0
@@ -65,3 +65,41 @@ def test_model_refuses_cpu_compute_and_keeps_state_dict_contract():
     # parameters alias one flat buffer
     p = next(m.parameters())
     assert p.data_ptr() == m.flat_params.data_ptr()
+
+
+def test_undersized_caller_buffers_are_rejected_before_anything_is_enqueued():
+    """include/dvs.h, code 14: records_bytes / n_params / workspace_bytes / state_bytes below what the shape needs come
+    back as an error (with the needed size in dvs_last_error) instead of a silent out-of-bounds device access.  The check
+    runs before any HIP call, so it is testable on a CPU-only box with dummy non-null pointers."""
+    lib = dl.load()
+    shape = dl.make_shape(64, 15, 15)
+    sb = ctypes.byref(shape)
+    rec_need = 64 * dl.record_bytes(lib, shape)
+    ws_need = lib.dvs_workspace_bytes(sb)
+    n_params = lib.dvs_param_count(sb)
+    dummy = ctypes.c_void_p(4096)           # never dereferenced: every call below fails validation first
+
+    def last():
+        return lib.dvs_last_error().decode()
+    assert lib.dvs_pack_features(sb, dummy, dummy, dummy, dummy, dummy, rec_need - 1, dummy, None) == 14
+    assert "records_bytes" in last() and str(rec_need) in last()
+    assert lib.dvs_build_records(sb, dummy, dummy, dummy, rec_need - 1, dummy, None) == 14
+    fwd = lambda rb, npar, wb: lib.dvs_loss_forward(sb, dummy, rb, dummy, npar, dummy, wb, None, None, dummy, None, None,
+                                                    None)
+    assert fwd(rec_need - 1, n_params, ws_need) == 14 and "records_bytes" in last()
+    assert fwd(rec_need, n_params - 1, ws_need) == 14 and "n_params" in last()
+    assert fwd(rec_need, n_params, ws_need - 4) == 14 and "workspace_bytes" in last() and str(ws_need) in last()
+    assert lib.dvs_loss_backward(sb, dummy, rec_need, dummy, n_params, dummy, ws_need - 4, dummy, dummy, None) == 14
+    assert lib.dvs_loss_backward(sb, dummy, rec_need, dummy, n_params - 1, dummy, ws_need, dummy, dummy, None) == 14
+    assert lib.dvs_encode(sb, dummy, rec_need, dummy, n_params, dummy, ws_need - 4, dummy, dummy, None) == 14
+    assert lib.dvs_decode(sb, dummy, n_params, dummy, ws_need, dummy, rec_need, dummy, None, dummy,
+                          64 * dl.DECODE_STATE_BYTES - 1, None) == 14
+    assert "state_bytes" in last()
+    assert lib.dvs_decode(sb, dummy, n_params, dummy, ws_need - 4, dummy, rec_need, dummy, None, dummy,
+                          64 * dl.DECODE_STATE_BYTES, None) == 14
+    # a bigger batch against buffers sized for a smaller one: the classic mistake this argument exists for
+    big = dl.make_shape(128, 15, 15)
+    assert lib.dvs_loss_forward(ctypes.byref(big), dummy, rec_need, dummy, n_params, dummy, ws_need, None, None, dummy, None,
+                                None, None) == 14
+    # null pointers are still code 10 and bad shapes 1..5
+    assert lib.dvs_loss_forward(sb, None, rec_need, dummy, n_params, dummy, ws_need, None, None, dummy, None, None, None) == 10

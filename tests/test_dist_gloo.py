@@ -38,21 +38,25 @@ def _worker(rank, world, port, out):
     total, recon, kld = po.loss_direct(P, cfg, shard, training=True, eps=eps_all[lo:hi])
     total.backward()
     g = _flat({k: v.grad for k, v in P.items()}, names)
-    # the product's layout (PaceVaeV3.bind_flat_grads): the 4 loss scalars sit right behind the gradient in ONE
-    # allocation, so allreduce_gradients sends both in a single collective; rank 1 uses separate tensors (two calls) —
-    # both layouts must give the same sums
+    # the product's layout (PaceVaeV3.bind_flat_grads): the 5 step scalars [total, recon, kld, non-finite flag,
+    # invalid-features flag] sit right behind the gradient in ONE allocation (followed by 3 rank-local words that must NOT
+    # travel), so allreduce_gradients sends both in a single collective; rank 1 builds the same message by hand.  Rank 1 raises the invalid-features flag: every rank must see it afterwards (they
+    # all skip the update and raise, train.train_batch).
+    mine = [float(total), float(recon), float(kld), 0.0, float(rank == 1)]
     if rank == 0:
-        both = torch.zeros(g.numel() + 4)
-        flat, losses = both[:g.numel()], both[g.numel():]
+        both = torch.zeros(g.numel() + 8)
+        flat, losses = both[:g.numel()], both[g.numel():g.numel() + 5]
         flat.copy_(g)
-        losses.copy_(torch.tensor([float(total), float(recon), float(kld), 0.0]))
+        losses.copy_(torch.tensor(mine))
+        both[-1] = 123.0                          # rank-local status word
         ddist.allreduce_gradients(flat, losses)
+        assert both[-1] == 123.0 and both[-2] == 0.0 and both[-3] == 0.0
     else:
-        flat = g.clone()
-        losses = torch.tensor([float(total), float(recon), float(kld), 0.0])
-        both = torch.cat([flat, losses])
+        both = torch.cat([g, torch.tensor(mine)])        # same collective shape as rank 0's single call
         dist.all_reduce(both)
-        flat, losses = both[:g.numel()].clone(), both[g.numel():].clone()
+        flat, losses = both[:g.numel()], both[g.numel():]
+    assert losses[4] == 1.0 and losses[3] == 0.0
+    flat, losses = flat.clone(), losses.clone()
     # clip AFTER the reduce, then replicated Adam
     coef = min(1.0, 1.0 / (float(flat.norm()) + 1e-6))
     flat_p = _flat(params, names).clone().requires_grad_(True)

@@ -83,8 +83,15 @@ def test_emu_train0_golden_and_adam_step():
     exp_avg_sq = np.zeros_like(m.flat)
     scratch = np.zeros(320, np.float32)
     p = m.flat.copy()
+    # a raised guard (non-finite loss / invalid batch) must leave parameters, moments and gradients untouched
+    for guard in ([1.0, 0.0], [0.0, 1.0]):
+        p0, f0 = p.copy(), flat.copy()
+        rc = m.lib.dvs_clip_adam(m.P, ptr(p), ptr(flat), ptr(exp_avg), ptr(exp_avg_sq), 1e-4, 0.9, 0.999, 1e-8, 1, 1.0,
+                                 ptr(scratch), ptr(np.asarray(guard, np.float32)), None)
+        assert rc == 0 and np.array_equal(p, p0) and np.array_equal(flat, f0)
+        assert not exp_avg.any() and not exp_avg_sq.any()
     rc = m.lib.dvs_clip_adam(m.P, ptr(p), ptr(flat), ptr(exp_avg), ptr(exp_avg_sq), 1e-4, 0.9, 0.999, 1e-8, 1, 1.0,
-                             ptr(scratch), None)
+                             ptr(scratch), ptr(np.zeros(2, np.float32)), None)
     assert rc == 0
     assert abs(np.sqrt(scratch[0]) - gn) / gn < 1e-5
     worst_big = 0.0

@@ -41,14 +41,16 @@ def test_emu_decode_equals_oracle_decode(name, B, seed):
     rng = np.random.default_rng(seed)
     zz = np.ascontiguousarray(z["eval/mu"][:B])
     U = rng.random((B, cfg.N, cfg.N)).astype(np.float32)
-    assert lib.dvs_decode(ctypes.byref(shape), ptr(flat), ptr(ws), ptr(rec), ptr(zz), ptr(U), ptr(state), None) == 0
+    assert lib.dvs_decode(ctypes.byref(shape), ptr(flat), flat.size, ptr(ws), ws.nbytes, ptr(rec), rec.nbytes, ptr(zz), ptr(U),
+                          ptr(state), state.nbytes, None) == 0
     got = parse_states(state, B)
     ref = odec.decode(params, cfg, torch.from_numpy(zz), U)
     for (nv, lab, edges, fin), g in zip(got, ref):
         assert nv == g.nv and lab == g.labels and edges == sorted(g.edges) and fin == g.finished
     # training shapes are refused
     bad = dl.make_shape(B, cfg.N, cfg.C, True, 0.15)
-    assert lib.dvs_decode(ctypes.byref(bad), ptr(flat), ptr(ws), ptr(rec), ptr(zz), ptr(U), ptr(state), None) != 0
+    assert lib.dvs_decode(ctypes.byref(bad), ptr(flat), flat.size, ptr(ws), ws.nbytes, ptr(rec), rec.nbytes, ptr(zz), ptr(U),
+                          ptr(state), state.nbytes, None) != 0
 
 
 def test_oracle_decode_reproduces_the_published_asia_reconstruction():

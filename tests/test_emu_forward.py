@@ -48,13 +48,13 @@ def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     status = np.zeros(1, np.int32)
     tm = np.ascontiguousarray(f["target_masks"]).astype(np.uint8)
     assert lib.dvs_pack_features(ctypes.byref(shape), ptr(f["vertex_label_features"]), ptr(f["vertex_position_features"]),
-                                 ptr(f["adjacency_matrices"]), ptr(tm), ptr(rec_a), ptr(status), None) == 0
+                                 ptr(f["adjacency_matrices"]), ptr(tm), ptr(rec_a), rec_a.nbytes, ptr(status), None) == 0
     assert status[0] == 0
     cb = encode_graphs(graphs, n)
     lab = np.ascontiguousarray(cb.labels.numpy())
     pr = np.ascontiguousarray(cb.preds.numpy())
     rec_b = np.zeros(B * RB, np.uint8)
-    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab), ptr(pr), ptr(rec_b), ptr(status), None) == 0
+    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab), ptr(pr), ptr(rec_b), rec_b.nbytes, ptr(status), None) == 0
     assert status[0] == 0
     assert np.array_equal(rec_a, rec_b)
     # non-identity positions occur (the order quirk is exercised)
@@ -63,7 +63,8 @@ def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     # bad label -> status bit 0
     lab2 = lab.copy()
     lab2[0, 0] = card + 5
-    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab2), ptr(pr), ptr(rec_b), ptr(status), None) == 0
+    assert lib.dvs_build_records(ctypes.byref(shape), ptr(lab2), ptr(pr), ptr(rec_b), rec_b.nbytes, ptr(status),
+                                 None) == 0
     assert status[0] & 1
     # dvs_pack_features' own checks: a mask head that differs from head 0 -> bit 1; a token that may not attend itself -> bit 2;
     # a label row that is not one-hot -> bit 0
@@ -72,7 +73,8 @@ def test_emu_build_records_matches_pack_of_dense_features(n, card, seed):
     def pack_status(lab1h, masks):
         st = np.zeros(1, np.int32)
         assert lib.dvs_pack_features(ctypes.byref(shape), ptr(lab1h), ptr(f["vertex_position_features"]),
-                                     ptr(f["adjacency_matrices"]), ptr(masks), ptr(rec_a), ptr(st), None) == 0
+                                     ptr(f["adjacency_matrices"]), ptr(masks), ptr(rec_a), rec_a.nbytes, ptr(st),
+                                     None) == 0
         return int(st[0])
     tm4 = tm.reshape(B, 8, N, N)
     head = tm4.copy()

@@ -7,6 +7,11 @@ from oracle import features as ofeat
 from oracle import pace_oracle as po
 from oracle.rng import DeviceMasks
 from tests.helpers import CONFIGS, grad_err, graphs_from, load_golden, load_npz, rel
+from tests.relu_trace import grad_errors, oracle_on_device_piece, record
+
+# Gradient bound of the deterministic parity tests, as a fraction of the tensor maximum (the old 2e-3 was 50x
+# what is measured; measured worst is printed by every test and kept in gpurun_out/parity_report.json).
+GRAD_BOUND = 2e-4
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -35,7 +40,8 @@ def test_loss_direct_and_autograd_match_reference_golden(name):
     assert abs(recon.item() - float(z["eval/recon"])) < 1e-4 * max(1.0, abs(float(z["eval/recon"])))
     total.backward()
     err, worst = grad_err({k: p.grad for k, p in model.named_parameters()}, z, "eval/grad/")
-    assert err < 2e-3, (worst, err)
+    record(f"golden_eval[{name}]", elbo_rel=rel(total.item(), z["eval/total"]), grad_err=err, worst=worst)
+    assert err < GRAD_BOUND, (worst, err)
 
 
 @pytest.mark.parametrize("name", ["n12c12", "asia_rand"])
@@ -49,19 +55,34 @@ def test_train_mode_dropout0_injected_eps_and_one_step(name):
     gn = np.sqrt(sum(float((z[k].astype(np.float64) ** 2).sum()) for k in z.files if k.startswith("train0/grad/")))
     coef = min(1.0, 1.0 / (gn + 1e-6))
 
-    def check_step(model):
-        # Adam's first step moves every parameter by lr * g / (|g| + 1e-8): entries whose clipped gradient is above 1e-7
-        # must land on the reference's value (measured: 1.4e-7); below that the step direction is rounding noise in ANY
-        # implementation — e.g. the key bias of every attention, whose true gradient is exactly zero (softmax shift
-        # invariance) — and only the size of the move is bounded (at most 2 lr apart).
-        worst = 0.0
+    def check_step(model, tag, clipped):
+        """(1) EVERY entry: the update equals Adam's first step applied to the path's own clipped gradient,
+        p - lr * g / (|g| + 1e-8) — pins the optimiser kernel on all 108 tensors, also where the direction is noise.
+        (2) Entries whose clipped REFERENCE gradient is above 1e-7 land on the reference's parameters (measured 1.4e-7):
+        below that the step direction is rounding noise in ANY implementation — e.g. the key bias of every attention,
+        whose true gradient is exactly zero (softmax shift invariance) — and only the size of the move is bounded
+        (2 lr).  (3) The share of entries outside the pinned set is asserted (and printed): the clip coefficient of
+        these cases is 3e-4 / 3e-5, which pushes 2.8 % / 6.1 % of the clipped gradient entries below 1e-7."""
+        worst, worst_formula = 0.0, 0.0
+        unsure_total, n_total = 0, 0
         for k, p in model.state_dict().items():
-            err = np.abs(p.cpu().numpy() - z["step/param/" + k])
+            new = p.cpu().numpy()
+            g = clipped[k].cpu().numpy().astype(np.float64)
+            formula = params[k].numpy().astype(np.float64) - 1e-4 * g / (np.abs(g) + 1e-8)
+            # fp32 rounding of the stored parameter (half an ulp of |p|) + of the 1e-4 step itself
+            worst_formula = max(worst_formula, float((np.abs(new - formula) / (1.2e-7 * np.maximum(1.0, np.abs(new)) + 1e-10)).max()))
+            err = np.abs(new - z["step/param/" + k])
             sure = np.abs(z["train0/grad/" + k]) * coef > 1e-7
             assert err.max() < 2.01e-4, k
+            n_total += sure.size
+            unsure_total += int((~sure).sum())
             if sure.any():
                 worst = max(worst, float(err[sure].max()))
+        record(f"adam_step[{name},{tag}]", pinned_worst=worst, own_gradient_formula_worst=worst_formula,
+               unpinned_fraction=unsure_total / n_total)
         assert worst < 1e-6
+        assert worst_formula < 1.0               # in units of the fp32 rounding allowance above
+        assert unsure_total / n_total < 0.07
 
     # (a) reference sequence with a stock optimiser
     model = build_model(cfg, params, dropout=0.0).train()
@@ -72,10 +93,11 @@ def test_train_mode_dropout0_injected_eps_and_one_step(name):
     assert rel(total.item(), z["train0/total"]) < 1e-4
     total.backward()
     err, worst = grad_err({k: p.grad for k, p in model.named_parameters()}, z, "train0/grad/")
-    assert err < 2e-3, (worst, err)
+    record(f"golden_train0[{name}]", elbo_rel=rel(total.item(), z["train0/total"]), grad_err=err, worst=worst)
+    assert err < GRAD_BOUND, (worst, err)
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
     opt.step()
-    check_step(model)
+    check_step(model, "stock", {k: p.grad for k, p in model.named_parameters()})
     # (b) fused path
     model2 = build_model(cfg, params, dropout=0.0).train()
     fo = dopt.Adam(model2.parameters(), lr=1e-4).attach(model2)
@@ -83,31 +105,42 @@ def test_train_mode_dropout0_injected_eps_and_one_step(name):
     fo.step(max_grad_norm=1.0)
     assert rel(losses[0].item(), z["train0/total"]) < 1e-4
     assert abs(fo.grad_norm.item() - gn) / gn < 1e-4
-    check_step(model2)
+    check_step(model2, "fused", {k: p.grad for k, p in model2.named_parameters()})      # k_adam clips .grad in place
 
 
-@pytest.mark.parametrize("name,B", [("n12c12", 48), ("asia_rand", 32)])
-def test_train_mode_dropout_on_matches_oracle_with_device_masks(name, B):
-    cfg, params, graphs, z = load_golden(name)
-    graphs = graphs[:B]
-    model = build_model(cfg, params, dropout=0.15).train()
-    model.seed(77)
-    model.dag_offset = 5
+def dropout_on_parity(tag, model, params, cfg, graphs, seed, dag_offset, bound=GRAD_BOUND):
+    """Train mode, dropout ON, the device's own masks injected into the oracle: ELBO < 1e-4, gradients within `bound` of
+    the tensor maximum on the SAME linear piece of the network (tests/relu_trace.py: ReLU sign disagreements at
+    near-zero pre-activations are counted, must be genuine ties, and the oracle is re-evaluated on the device's piece)."""
+    B = len(graphs)
+    model.train()
+    model.zero_grad(set_to_none=True)        # .grad may alias flat_grads of an earlier fused step: autograd accumulates
+    model.seed(seed)
+    model.dag_offset = dag_offset
     f = feats_for(model, graphs)
     total, recon, kld = model.loss_direct(f)
     total.backward()
-    seed = (77 << 32) | 1                                  # PaceVaeV3._next_seed: (seed << 32) | step
-    masks = DeviceMasks(seed, 0.15, dag_offset=5)
-    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    f_np = ofeat.dense_features(graphs, cfg.card)
-    t, r, k = po.loss_direct(P, cfg, ofeat.to_torch(f_np), training=True, eps=torch.from_numpy(masks.eps(B)), masks=masks)
-    t.backward()
-    assert rel(total.item(), t.detach()) < 1e-4 and rel(kld.item(), k.detach()) < 1e-4
-    scale = max(float(p.grad.abs().max()) for p in P.values())
-    for kname, p in model.named_parameters():
-        ref = P[kname].grad.numpy()
-        e = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale)
-        assert e < 3e-3, (kname, e)
+    masks = DeviceMasks((seed << 32) | 1, 0.15, dag_offset=dag_offset)          # PaceVaeV3._next_seed: (seed << 32) | step
+    f_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()}
+    t, k, g_piece, g_plain, info = oracle_on_device_piece(model, params, cfg, f_cpu, B, True,
+                                                          eps=torch.from_numpy(masks.eps(B)), masks=masks)
+    got = {n: p.grad for n, p in model.named_parameters()}
+    err, worst, _ = grad_errors(got, g_piece)
+    err_plain, worst_plain, _ = grad_errors(got, g_plain)
+    record(tag, elbo_rel=rel(total.item(), t), grad_err=err, worst=worst, grad_err_plain_oracle=err_plain,
+           worst_plain=worst_plain, **info)
+    model.dag_offset = 0
+    model.zero_grad(set_to_none=True)
+    assert rel(total.item(), t) < 1e-4 and rel(kld.item(), k) < 1e-4
+    assert info["relu_flips"] <= max(4, 2e-5 * info["relu_units"]), info
+    assert err < bound, (worst, err, info)
+
+
+@pytest.mark.parametrize("name,B,seed", [("n12c12", 48, 77), ("asia_rand", 32, 77), ("n12c12", 48, 5), ("n12c12", 48, 6)])
+def test_train_mode_dropout_on_matches_oracle_with_device_masks(name, B, seed):
+    cfg, params, graphs, z = load_golden(name)
+    model = build_model(cfg, params, dropout=0.15)
+    dropout_on_parity(f"dropout_on[{name},B={B},seed={seed}]", model, params, cfg, graphs[:B], seed, 5)
 
 
 def test_encode_direct_known_answer():
@@ -170,6 +203,9 @@ def test_full_size_properties_n12_b4096():
     model.dag_offset = 0
     assert rel(lsum, l1[0].item()) < 1e-5
     assert (tot - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
+    # one 512-DAG slice of the SAME batch (global DAG indices 1536..2047, i.e. the masks the full batch drew) against the
+    # CPU oracle: train mode, dropout on, ELBO + all 108 gradients (the headline shape had no oracle comparison)
+    dropout_on_parity("full_size_n12_b4096_slice512", model, params, cfg, graphs[1536:2048], 1, 1536)
     opt = dopt.Adam(model.parameters(), lr=1e-3).attach(model)
     first = None
     for step in range(12):
@@ -218,9 +254,12 @@ def test_sachs_shape_n11():
     t.backward()
     assert rel(total.item(), t.detach()) < 1e-4
     scale = max(float(p.grad.abs().max()) for p in P.values())
+    worst = 0.0
     for name, p in model.named_parameters():
         ref = P[name].grad.numpy()
-        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale) < 2e-3, name
+        worst = max(worst, float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale))
+    record("sachs_n11_eval", elbo_rel=rel(total.item(), t.detach()), grad_err=worst)
+    assert worst < GRAD_BOUND
 
 
 def test_compact_batch_front_end_equals_dense_features_path():
@@ -290,27 +329,10 @@ def test_alarm_n37_b2048_wide_path():
     # device-side front-end (64-bit rows) gives the same records
     cb = encode_graphs(graphs, 37).to(DEV)
     assert [x.item() for x in model.loss_direct(cb)] == [total.item(), recon.item(), kld.item()]
-    # dropout-on gradients on the last 24 DAGs (they include the chains)
-    sub = graphs[-24:]
-    fs = model.prepare_features(sub)
-    model.train()
-    model.seed(9)
-    model.dag_offset = 3
-    tt, rr, kk = model.loss_direct(fs)
-    tt.backward()
-    masks = DeviceMasks((9 << 32) | 1, 0.15, dag_offset=3)
-    P = {k2: v.clone().requires_grad_(True) for k2, v in params.items()}
-    fs_cpu = {k2: (v.cpu() if torch.is_tensor(v) else v) for k2, v in fs.items()}
-    to, ro, ko = po.loss_direct(P, cfg, fs_cpu, training=True, eps=torch.from_numpy(masks.eps(24)), masks=masks)
-    to.backward()
-    assert rel(tt.item(), to.detach()) < 1e-4 and rel(kk.item(), ko.detach()) < 1e-4
-    scale = max(float(p.grad.abs().max()) for p in P.values())
-    for name, p in model.named_parameters():
-        ref = P[name].grad.numpy()
-        e = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-4 * scale)
-        assert e < 3e-3, (name, e)
-    model.dag_offset = 0
-    model.zero_grad(set_to_none=True)
+    # dropout-on gradients on the last 24 DAGs (they include the chains), several mask draws: round 1 saw 3.0e-3 on
+    # encoder.layers.2.linear1.weight under one draw and < 1e-4 under others — isolated ReLU ties (tests/relu_trace.py)
+    for seed in (9, 10, 11):
+        dropout_on_parity(f"dropout_on[alarm n37,B=24,seed={seed}]", model, params, cfg, graphs[-24:], seed, 3)
     # full-size properties
     model.seed(1)
     l1 = model.loss_and_grad(f).clone()
@@ -395,3 +417,137 @@ def test_train_model_epoch_loop_and_checkpoint_reload(tmp_path):
     model.eval()
     f = model.prepare_features(graphs[:16])
     assert torch.equal(model.encode_direct(f)[0], fresh.encode_direct(f)[0])
+
+
+def test_refused_launch_comes_back_as_an_error_code():
+    """include/dvs.h code 20: a kernel launch the HIP runtime refuses (here: 200 KB of dynamic LDS on a 160 KB CU) must
+    surface as a non-zero return code with the kernel's name and the HIP error string — not as success with stale results."""
+    from dags_vae_search_amd import _lib as dl
+    lib = dl.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.dvs_debug_launch(1024, stream) == 0
+    rc = lib.dvs_debug_launch(200 * 1024, stream)
+    msg = lib.dvs_last_error().decode()
+    assert rc == 20 and "k_debug_empty" in msg and "HIP error" in msg, (rc, msg)
+    with pytest.raises(RuntimeError, match="k_debug_empty"):
+        dl.check(lib, rc, "dvs_debug_launch")
+    assert lib.dvs_debug_launch(1024, stream) == 0            # the failure is not sticky
+    torch.cuda.synchronize()
+
+
+def test_nonfinite_or_invalid_batch_leaves_weights_and_moments_untouched():
+    """the reference raises inside loss_direct (pace.py:97-98) — before backward, clip and step
+    (main.py:111-116) — so a NaN loss or an invalid batch leaves the model intact.  The fused step has its optimiser
+    kernels enqueued before the host can know; they carry the two flags as a device-side guard (dvs_clip_adam)."""
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.train import train_batch
+    cfg, params, graphs, z = load_golden("n12c12")
+    model = build_model(cfg, params).train()
+    f = feats_for(model, graphs)
+    opt = dopt.Adam(model.parameters(), lr=1e-3).attach(model)
+    for _ in range(2):
+        train_batch(f, model, opt)
+
+    def snapshot():
+        st = opt.state[next(iter(opt.param_groups[0]["params"]))]
+        return model.flat_params.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"]
+
+    # (1) invalid batch: a label row that is not one-hot
+    before = snapshot()
+    bad = dict(f)
+    bad["vertex_label_features"] = f["vertex_label_features"] * 0.5
+    with pytest.raises(ValueError, match="feature invariants"):
+        train_batch(bad, model, opt)
+    torch.cuda.synchronize()
+    after = snapshot()
+    assert all(torch.equal(a, b) for a, b in zip(before[:3], after[:3])) and before[3] == after[3] == 2
+    # (2) non-finite loss: exp(logvar) overflows
+    with torch.no_grad():
+        model.fc2.bias.fill_(1e30)
+    before = snapshot()
+    with pytest.raises(ValueError, match="NaN"):
+        train_batch(f, model, opt)
+    torch.cuda.synchronize()
+    after = snapshot()
+    assert all(torch.equal(a, b) for a, b in zip(before[:3], after[:3])) and before[3] == after[3] == 2
+    # (3) the model is still usable: repair, step, and the step count moves on
+    with torch.no_grad():
+        model.fc2.bias.zero_()
+    loss_value, _, _ = train_batch(f, model, opt)
+    assert np.isfinite(loss_value) and opt._steps == 3 and not torch.equal(model.flat_params, after[0])
+
+
+def test_fused_adam_state_dict_round_trip():
+    """the fused optimiser's moments and step live in ordinary optimiser state: state_dict() -> a fresh
+    optimiser on a fresh model -> load_state_dict() continues bit for bit like the uninterrupted run, and that run tracks
+    torch.optim.Adam over the autograd path."""
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.train import train_batch
+    cfg, params, graphs, z = load_golden("n12c12")
+
+    def run(model, opt, steps, first_step):
+        for i in range(steps):
+            model._seed, model._step = 5, first_step + i            # same masks in every run
+            train_batch(f, model, opt)
+    a = build_model(cfg, params).train()
+    f = feats_for(a, graphs)
+    oa = dopt.Adam(a.parameters(), lr=1e-3).attach(a)
+    run(a, oa, 3, 0)
+    sd_model = {k: v.clone() for k, v in a.state_dict().items()}
+    sd_opt = oa.state_dict()
+    assert len(sd_opt["state"]) == 1 and sd_opt["state"][0]["step"] == 3
+    assert sd_opt["state"][0]["exp_avg"].abs().sum() > 0
+    sd_opt = {"state": {k: {kk: (vv.cpu().clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                        for k, v in sd_opt["state"].items()}, "param_groups": sd_opt["param_groups"]}   # as torch.save/load
+    run(a, oa, 2, 3)
+    b = build_model(cfg, sd_model).train()
+    ob = dopt.Adam(b.parameters(), lr=1e-3).attach(b)
+    ob.load_state_dict(sd_opt)
+    run(b, ob, 2, 3)
+    assert ob._steps == 5 and torch.equal(a.flat_params, b.flat_params)
+    # without the restored state the runs differ (the test would not notice a silent restart otherwise)
+    c = build_model(cfg, sd_model).train()
+    oc = dopt.Adam(c.parameters(), lr=1e-3).attach(c)
+    run(c, oc, 2, 3)
+    assert not torch.equal(a.flat_params, c.flat_params)
+    # stock Adam over the autograd-wrapped kernels, same masks: same trajectory up to rounding
+    d = build_model(cfg, params).train()
+    od = torch.optim.Adam(d.parameters(), lr=1e-3)
+    run(d, od, 5, 0)
+    assert (a.flat_params - d.flat_params).abs().max().item() < 2e-5
+
+
+def test_data_parallel_step_over_rccl_world1_equals_single_gpu_step(tmp_path):
+    """train_batch(group=True) had never run through RCCL.  One rank, backend nccl (= RCCL): the all-reduce of
+    [flat gradient | loss scalars], clip-after-reduce and the guarded Adam give bit-identical parameters and losses to the
+    single-GPU fused step."""
+    import torch.distributed as dist
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.train import train_batch
+    cfg, params, graphs, z = load_golden("n12c12")
+    a = build_model(cfg, params).train()
+    b = build_model(cfg, params).train()
+    f = feats_for(a, graphs)
+    oa = dopt.Adam(a.parameters(), lr=1e-3).attach(a)
+    ob = dopt.Adam(b.parameters(), lr=1e-3).attach(b)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    try:
+        for step in range(3):
+            a.seed(step)
+            b.seed(step)
+            la = train_batch(f, a, oa)
+            lb = train_batch(f, b, ob, group=True)
+            assert la[0] == lb[0] and la[1].item() == lb[1].item() and la[2].item() == lb[2].item()
+        assert torch.equal(a.flat_params, b.flat_params)
+        bad = dict(f)
+        bad["vertex_label_features"] = f["vertex_label_features"] * 0.5
+        before = b.flat_params.clone()
+        with pytest.raises(ValueError):
+            train_batch(bad, b, ob, group=True)
+        assert torch.equal(before, b.flat_params)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -7,6 +7,7 @@ profiles/.  Usage:
     tools/rocprof_summary.py hbm-csv <fetch_pass.csv> <write_pass.csv> <batch>   > profiles/rNN_pmc_hbm.csv
     tools/rocprof_summary.py pmc-csv <x_counter_collection.csv> [...]   > profiles/rNN_pmc.csv  (per-dispatch averages;
                                                                         from rocprofv3 --pmc ... --output-format csv)
+    tools/rocprof_summary.py sq-derived <rNN_pmc_sq.csv>                (fractions of wave cycles, matrix-pipe busy share)
 Counter passes are collected separately (rocprofv3 --kernel-trace --pmc A B ...; gpurun refuses --pmc with --stats)."""
 import collections
 import sqlite3
@@ -81,8 +82,9 @@ def pmc_csv(paths):
 
 
 def hbm_csv(fetch_path, write_path, batch):
-    """Two --pmc passes (FETCH_SIZE, WRITE_SIZE; both in KB) -> per-kernel HBM traffic per launch and per DAG.
-    FETCH_SIZE is doubled: gfx950 counts its 128-byte read requests as 64 (MI355X_MICROARCH.md, HBM section)."""
+    """Two --pmc passes (FETCH_SIZE, WRITE_SIZE; both in KB) -> per-kernel HBM traffic per launch and per DAG, the launches
+    per train step, and a TOTAL row per step.  FETCH_SIZE is doubled: gfx950 counts its 128-byte read requests as 64
+    (MI355X_MICROARCH.md, HBM section)."""
     import csv
 
     def avg(path, counter):
@@ -91,12 +93,35 @@ def hbm_csv(fetch_path, write_path, batch):
             k = short(r["Kernel_Name"])
             if k.startswith("k_") and r["Counter_Name"] == counter:
                 acc[k].append(float(r["Counter_Value"]))
-        return {k: sum(v) / len(v) for k, v in acc.items()}
-    fetch, write = avg(fetch_path, "FETCH_SIZE"), avg(write_path, "WRITE_SIZE")
-    print("kernel,fetch_KB_corrected,write_KB,bytes_per_DAG")
-    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):
+        steps = max(len(acc.get("k_pack", [])), len(acc.get("k_pack_w", [])), len(acc.get("k_build_records", [])), 1)
+        return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) / steps for k, v in acc.items()}
+    (fetch, per_step), (write, _) = avg(fetch_path, "FETCH_SIZE"), avg(write_path, "WRITE_SIZE")
+    print("kernel,launches_per_step,fetch_KB_corrected,write_KB,bytes_per_DAG")
+    total = 0.0
+    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0)) * per_step[k]):
         f, w = 2 * fetch[k], write.get(k, 0.0)
-        print(f"{k},{f:.0f},{w:.0f},{(f + w) * 1024 / batch:.0f}")
+        total += (f + w) * 1024 * per_step[k]
+        print(f"{k},{per_step[k]:.2f},{f:.0f},{w:.0f},{(f + w) * 1024 / batch:.0f}")
+    print(f"TOTAL_PER_STEP,1,,,{total / batch:.0f}")
+
+
+def sq_derived(path):
+    """Derived figures from an SQ counter pass (pmc-csv output): waves parked / issue-stalled / issuing as fractions of
+    SQ_WAVE_CYCLES (all quad-cycles), and the matrix pipe's busy share for 512-thread workgroups at one per CU (two waves
+    per SIMD share a pipe): SQ_VALU_MFMA_BUSY_CYCLES (cycles) / (4 * SQ_WAVE_CYCLES / 2)."""
+    import csv
+    rows = list(csv.DictReader(open(path)))
+    print("kernel,wait_any_frac,issue_stall_frac,issuing_frac,valu_frac,mfma_pipe_busy,lds_conflict_per_lds_inst")
+    for r in rows:
+        try:
+            wc = float(r["SQ_WAVE_CYCLES"])
+            waves_per_simd = max(1.0, float(r["wg_size"]) / 256.0)
+            print(f"{r['kernel']},{float(r['SQ_WAIT_ANY']) / wc:.3f},{float(r['SQ_WAIT_INST_ANY']) / wc:.3f},"
+                  f"{float(r['SQ_ACTIVE_INST_ANY']) / wc:.3f},{float(r['SQ_ACTIVE_INST_VALU']) / wc:.3f},"
+                  f"{float(r['SQ_VALU_MFMA_BUSY_CYCLES']) * waves_per_simd / (4 * wc):.3f},"
+                  f"{float(r['SQ_LDS_BANK_CONFLICT']) / max(float(r['SQ_INSTS_LDS']), 1.0):.2f}")
+        except (KeyError, ValueError, ZeroDivisionError):
+            continue
 
 
 if __name__ == "__main__":
@@ -111,5 +136,7 @@ if __name__ == "__main__":
         hbm_csv(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     elif mode == "pmc-csv":
         pmc_csv(sys.argv[2:])
+    elif mode == "sq-derived":
+        sq_derived(sys.argv[2])
     else:
         raise SystemExit(__doc__)

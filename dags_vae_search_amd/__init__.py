@@ -9,4 +9,5 @@ from .train import batch_test, load_model_state, train_batch, train_model  # noq
 from . import optim  # noqa: F401
 from .records import CompactBatch, CompactDagDataset, encode_graphs  # noqa: F401
 from .bic import BNLearnWrapper  # noqa: F401
+from .predictor_data import create_predictor_dataset, generate_predictor_graphs_batch, prepare_predictor_data  # noqa: F401
 from .datasets import LabeledDagDatasetInMemory, LabeledDagDatasetInMemoryTest  # noqa: F401

@@ -74,9 +74,17 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.dvs_bic_scores.restype = c_int
     lib.dvs_bic_scores.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]
+    lib.dvs_bic_parent_masks.restype = c_int
+    lib.dvs_bic_parent_masks.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_gp_predict.restype = c_int
     lib.dvs_gp_predict.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, c_void_p, c_void_p]
+    lib.dvs_gp_kernel.restype = c_int
+    lib.dvs_gp_kernel.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double, c_void_p,
+                                  c_void_p]
+    lib.dvs_gp_kernel_backward.restype = c_int
+    lib.dvs_gp_kernel_backward.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, ctypes.c_double,
+                                           ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dvs_clip_adam.restype = c_int
     # (n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard, stream)
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
@@ -91,7 +99,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_gp_predict",
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
 
 

@@ -85,5 +85,24 @@ class BNLearnWrapper:
                              "cells; sorted samples: 16 384 samples, 63 key bits)")
         return out
 
+    def score_compact(self, batch) -> torch.Tensor:
+        """BIC of a ``CompactBatch`` (records.py) that lives on the device -> float64 [B] on the device: the relabelling
+        (dvs_bic_parent_masks) and the scoring (dvs_bic_scores) are both HIP launches, nothing touches the host."""
+        labels = batch.labels.to(self.device).contiguous()
+        preds = batch.preds.to(self.device).contiguous()
+        B, n = labels.shape
+        assert n == self.n_vars, f"Expected {self.n_vars} vertices, but got {n}"                             # bnlearn.py:34
+        parents = torch.empty(B, n, dtype=torch.int64, device=self.device)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        dl.check(self.lib, self.lib.dvs_bic_parent_masks(B, n, 1 if preds.dtype == torch.int64 else 0, p(labels), p(preds),
+                                                         p(parents), p(status),
+                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                 "dvs_bic_parent_masks")
+        out = self.score_masks(parents)
+        if int(status.item()) & 32:
+            raise AssertionError(f"Expected graph labels from 0 to {n - 1}")                                  # bnlearn.py:35
+        return out
+
     def score(self, labeled_graph, label_key: str = LABEL_KEY) -> float:
         return self.score_batch([labeled_graph], label_key)[0]

@@ -879,6 +879,19 @@ extern "C" int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, 
     return call_end("dvs_bic_scores");
 }
 
+extern "C" int dvs_bic_parent_masks_impl(int B, int n, int wide, const uint8_t* labels, const void* preds, uint64_t* parents,
+                                         int* status, void* stream);
+extern "C" int dvs_bic_parent_masks(int32_t batch, int32_t n_vars, int32_t preds_are_u64, const uint8_t* labels,
+                                    const void* preds, uint64_t* parents, int32_t* status, void* stream) {
+    if (batch <= 0) return fail(2, "dvs_bic_parent_masks: batch must be > 0");
+    if (n_vars < 1 || n_vars > DVS_WTOK) return fail(3, "dvs_bic_parent_masks: n_vars must be in [1, 48]");
+    if (!preds_are_u64 && n_vars > 16) return fail(12, "dvs_bic_parent_masks: 16-bit predecessor rows hold at most 16 vertices");
+    if (!labels || !preds || !parents || !status) return fail(10, "dvs_bic_parent_masks: null pointer");
+    call_begin();
+    if (int e = dvs_bic_parent_masks_impl(batch, n_vars, preds_are_u64 ? 1 : 0, labels, preds, parents, status, stream)) return e;
+    return call_end("dvs_bic_parent_masks");
+}
+
 extern "C" int dvs_gp_predict_impl(int B, int M, int D, const float* x, const float* z, const double* alpha,
                                    double outputscale, double lengthscale, double constant, double* out, void* stream);
 extern "C" int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, const float* x, const float* inducing,
@@ -890,6 +903,43 @@ extern "C" int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, co
     call_begin();
     if (int e = dvs_gp_predict_impl(batch, n_inducing, dim, x, inducing, alpha, outputscale, lengthscale, constant, out, stream)) return e;
     return call_end("dvs_gp_predict");
+}
+
+extern "C" int dvs_gp_kernel_impl(int na, int nb, int D, const float* xa, const float* xb, double outputscale, double lengthscale,
+                                  double* K, void* stream);
+extern "C" int dvs_gp_kernel_backward_impl(int na, int nb, int D, int symmetric, const float* xa, const float* xb,
+                                           double outputscale, double lengthscale, const double* G, double* dxa, double* rows,
+                                           void* stream);
+static int gp_check(const char* fn, int na, int nb, int dim, double outputscale, double lengthscale) {
+    char msg[160];
+    if (na <= 0 || nb <= 0 || dim <= 0 || dim > 32) {
+        snprintf(msg, sizeof(msg), "%s: sizes must be > 0 and dim <= 32", fn);
+        return fail(2, msg);
+    }
+    if (!(lengthscale > 0.0) || !(outputscale > 0.0)) {
+        snprintf(msg, sizeof(msg), "%s: lengthscale and outputscale must be > 0", fn);
+        return fail(5, msg);
+    }
+    return 0;
+}
+extern "C" int dvs_gp_kernel(int32_t na, int32_t nb, int32_t dim, const float* xa, const float* xb, double outputscale,
+                             double lengthscale, double* K, void* stream) {
+    if (int e = gp_check("dvs_gp_kernel", na, nb, dim, outputscale, lengthscale)) return e;
+    if (!xa || !xb || !K) return fail(10, "dvs_gp_kernel: null pointer");
+    call_begin();
+    if (int e = dvs_gp_kernel_impl(na, nb, dim, xa, xb, outputscale, lengthscale, K, stream)) return e;
+    return call_end("dvs_gp_kernel");
+}
+extern "C" int dvs_gp_kernel_backward(int32_t na, int32_t nb, int32_t dim, int32_t symmetric, const float* xa, const float* xb,
+                                      double outputscale, double lengthscale, const double* G, double* dxa, double* row_sums,
+                                      void* stream) {
+    if (int e = gp_check("dvs_gp_kernel_backward", na, nb, dim, outputscale, lengthscale)) return e;
+    if (!xa || !xb || !G || !dxa || !row_sums) return fail(10, "dvs_gp_kernel_backward: null pointer");
+    if (symmetric && na != nb) return fail(12, "dvs_gp_kernel_backward: symmetric needs na == nb");
+    call_begin();
+    if (int e = dvs_gp_kernel_backward_impl(na, nb, dim, symmetric, xa, xb, outputscale, lengthscale, G, dxa, row_sums, stream))
+        return e;
+    return call_end("dvs_gp_kernel_backward");
 }
 
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {

@@ -252,3 +252,176 @@ extern "C" int dvs_gp_predict_impl(int B, int M, int D, const float* x, const fl
     DVS_LAUNCH(k_gp_predict, dim3((B + 3) / 4), dim3(256), 0, (dvs_stream_t)stream, a);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// GP predictor, hyper-parameter training (reference loop src/predictors/gp.py:55-81 =
+// experiments/01_bn_asia/main.py:315-393: Adam on -ExactMarginalLogLikelihood of the SGPR model).  The two kernel-specific
+// pieces of one training iteration; the dense M x M / M x n factorisations in between are library calls of the host side
+// (predictor.py), the parameter update is dvs_clip_adam.
+//   k_gp_kernel      K[a][b] = o exp(-|xa_a - xb_b|^2 / (2 l^2)), float64 (K_uu needs all of it: its Cholesky factor is
+//                    ill-conditioned at M = 500), float32 points.
+//   k_gp_kernel_bwd  given G = dF/dK: row a's pull-backs  dxa_a = sum_b G'_ab K_ab (xb_b - xa_a) / l^2  (G' = G + G^T when
+//                    xa and xb are the same point set, K_uu) and the per-row partial sums of dF/dl = sum G K d^2 / l^3 and
+//                    dF/do = sum G K / o.  One wave per row a, lanes stride over b, fixed-order reduction: bitwise
+//                    reproducible.  K is recomputed from the points (a 32-dim distance) instead of read.
+// ---------------------------------------------------------------------------------------------------------
+struct GpKernArgs {
+    int na, nb, D, symmetric;
+    const float* xa;
+    const float* xb;
+    double outputscale, inv2l2, inv_l2, inv_l3, inv_o;
+    double* K;                   // forward: [na][nb]
+    const double* G;             // backward: [na][nb]
+    double* dxa;                 // backward: [na][D]
+    double* rows;                // backward: [na][2]: d/dl, d/do partials
+};
+constexpr int DVS_GP_MAXD = 32;
+__global__ __launch_bounds__(256) void k_gp_kernel(GpKernArgs a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)a.na * a.nb) return;
+    const int ra = (int)(i / a.nb), rb = (int)(i - (size_t)ra * a.nb);
+    const float* pa = a.xa + (size_t)ra * a.D;
+    const float* pb = a.xb + (size_t)rb * a.D;
+    double d2 = 0.0;
+    for (int k = 0; k < a.D; ++k) {
+        const double d = (double)pa[k] - (double)pb[k];
+        d2 = fma(d, d, d2);
+    }
+    a.K[i] = a.outputscale * exp(-d2 * a.inv2l2);
+}
+__device__ __forceinline__ double dvs_wave_sum_f64(double v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const long long bits = __double_as_longlong(v);
+        int lo = (int)(bits & 0xffffffffLL), hi = (int)(bits >> 32);
+        lo = __shfl_xor(lo, s);
+        hi = __shfl_xor(hi, s);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_gp_kernel_bwd(GpKernArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ra = blockIdx.x * 4 + wave;
+    if (ra >= a.na) return;
+    const float* pa = a.xa + (size_t)ra * a.D;
+    double xa[DVS_GP_MAXD], acc[DVS_GP_MAXD];
+#pragma unroll
+    for (int k = 0; k < DVS_GP_MAXD; ++k) {
+        xa[k] = k < a.D ? (double)pa[k] : 0.0;
+        acc[k] = 0.0;
+    }
+    double sl = 0.0, so = 0.0;
+    for (int rb = lane; rb < a.nb; rb += 64) {
+        const float* pb = a.xb + (size_t)rb * a.D;
+        double diff[DVS_GP_MAXD], d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DVS_GP_MAXD; ++k) {
+            diff[k] = k < a.D ? (double)pb[k] - xa[k] : 0.0;
+            d2 = fma(diff[k], diff[k], d2);
+        }
+        const double Kab = a.outputscale * exp(-d2 * a.inv2l2);
+        const double g = a.G[(size_t)ra * a.nb + rb];
+        const double w = g * Kab;
+        sl += w * d2;
+        so += w;
+        const double wr = a.symmetric ? (g + a.G[(size_t)rb * a.nb + ra]) * Kab : w;
+#pragma unroll
+        for (int k = 0; k < DVS_GP_MAXD; ++k) acc[k] = fma(wr, diff[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < DVS_GP_MAXD; ++k) {
+        const double s = dvs_wave_sum_f64(acc[k]);
+        if (lane == 0 && k < a.D) a.dxa[(size_t)ra * a.D + k] = s * a.inv_l2;
+    }
+    sl = dvs_wave_sum_f64(sl);
+    so = dvs_wave_sum_f64(so);
+    if (lane == 0) {
+        a.rows[2 * (size_t)ra] = sl * a.inv_l3;
+        a.rows[2 * (size_t)ra + 1] = so * a.inv_o;
+    }
+}
+
+static GpKernArgs gp_kern_args(int na, int nb, int D, const float* xa, const float* xb, double outputscale, double lengthscale) {
+    GpKernArgs a = {};
+    a.na = na;
+    a.nb = nb;
+    a.D = D;
+    a.xa = xa;
+    a.xb = xb;
+    a.outputscale = outputscale;
+    a.inv2l2 = 0.5 / (lengthscale * lengthscale);
+    a.inv_l2 = 1.0 / (lengthscale * lengthscale);
+    a.inv_l3 = 1.0 / (lengthscale * lengthscale * lengthscale);
+    a.inv_o = 1.0 / outputscale;
+    return a;
+}
+extern "C" int dvs_gp_kernel_impl(int na, int nb, int D, const float* xa, const float* xb, double outputscale, double lengthscale,
+                                  double* K, void* stream) {
+    GpKernArgs a = gp_kern_args(na, nb, D, xa, xb, outputscale, lengthscale);
+    a.K = K;
+    const size_t n = (size_t)na * nb;
+    DVS_LAUNCH(k_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (dvs_stream_t)stream, a);
+    return 0;
+}
+extern "C" int dvs_gp_kernel_backward_impl(int na, int nb, int D, int symmetric, const float* xa, const float* xb,
+                                           double outputscale, double lengthscale, const double* G, double* dxa, double* rows,
+                                           void* stream) {
+    GpKernArgs a = gp_kern_args(na, nb, D, xa, xb, outputscale, lengthscale);
+    a.symmetric = symmetric;
+    a.G = G;
+    a.dxa = dxa;
+    a.rows = rows;
+    DVS_LAUNCH(k_gp_kernel_bwd, dim3((unsigned)((na + 3) / 4)), dim3(256), 0, (dvs_stream_t)stream, a);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row codec -> BIC parent masks on the device (the relabelling of BNLearnWrapper.score, src/problem/bn/bnlearn.py:34-45:
+// graph vertex v stands for data-set variable labels[v]): parents[b][labels[v]] = OR over predecessors u of (1 << labels[u]).
+// One thread per (DAG, vertex).  status bit 5: the labels of a DAG are not a permutation of 0..n-1 (the reference asserts,
+// bnlearn.py:35) — that DAG's masks are zeroed.
+// ---------------------------------------------------------------------------------------------------------
+struct BicMaskArgs {
+    int B, n, wide;
+    const uint8_t* labels;       // [B][n]
+    const void* preds;           // [B][n] u16 (wide == 0) or u64
+    uint64_t* parents;           // [B][n]
+    int* status;
+};
+__global__ __launch_bounds__(256) void k_bic_parent_masks(BicMaskArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.n) return;
+    const int b = i / a.n, v = i - b * a.n;
+    const uint8_t* lab = a.labels + (size_t)b * a.n;
+    uint64_t seen = 0;
+    bool ok = true;
+    for (int u = 0; u < a.n; ++u) {
+        ok = ok && lab[u] < a.n;
+        seen |= 1ull << (lab[u] & 63);
+    }
+    ok = ok && seen == (a.n == 64 ? ~0ull : (1ull << a.n) - 1ull);
+    const uint64_t pr = a.wide ? ((const uint64_t*)a.preds)[i] : (uint64_t)((const uint16_t*)a.preds)[i];
+    uint64_t m = 0;
+    for (int u = 0; u < v; ++u)
+        if ((pr >> u) & 1ull) m |= 1ull << (lab[u] & 63);
+    if (!ok) {
+        atomicOr(a.status, 32);
+        a.parents[(size_t)b * a.n + v] = 0;
+        return;
+    }
+    a.parents[(size_t)b * a.n + lab[v]] = m;
+}
+extern "C" int dvs_bic_parent_masks_impl(int B, int n, int wide, const uint8_t* labels, const void* preds, uint64_t* parents,
+                                         int* status, void* stream) {
+    BicMaskArgs a;
+    a.B = B;
+    a.n = n;
+    a.wide = wide;
+    a.labels = labels;
+    a.preds = preds;
+    a.parents = parents;
+    a.status = status;
+    DVS_LAUNCH(k_bic_parent_masks, dim3((unsigned)((B * n + 255) / 256)), dim3(256), 0, (dvs_stream_t)stream, a);
+    return 0;
+}

@@ -36,7 +36,9 @@ def shard_features(features: Dict, rank: int, world: int, num_heads: int = 8) ->
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, losses: torch.Tensor, group=None):
-    """The step's ONE exchange: SUM all-reduce of the flat gradient and of the [total, recon, kld, flag] scalars
+    """Single-collective form of the step's exchange (kept for callers that want the loss scalars only at the end of the
+    step; ``train.train_batch`` all-reduces the five scalars right behind the forward on a side stream instead, so that the
+    host reads the global loss early, and the gradient alone here on the main stream).  The step's ONE exchange: SUM all-reduce of the flat gradient and of the [total, recon, kld, flag] scalars
     (RCCL over xGMI on GPUs, gloo in the CPU tests).  Clipping and Adam run AFTER it, replicated on every rank.
     ``PaceVaeV3.loss_and_grad`` keeps the four scalars right behind the gradient in one allocation, so both travel in a
     single collective (the message is ~1.2 MB: latency-bound, a second call would cost as much as the first)."""

@@ -315,11 +315,14 @@ class PaceVaeV3(nn.Module):
         eng.pack(f, check=check, zero_status=zero_status)
         return f["vertex_label_features"].shape[0]
 
-    def _early_read(self):
-        """Called between the forward and the backward of a fused step: the [losses, validation word] tail is final once
-        the forward has run, so its device->host copy (and the re-arming of the validation word) goes to a side stream
+    def _early_read(self, group=None, reduce_group=None):
+        """Called between the forward and the backward of a fused step: the [losses, flags | validation word] tail is final
+        once the forward has run, so its device->host copy (and the re-arming of the validation word) goes to a side stream
         behind an event.  The host then blocks only until the FORWARD is done — where the reference's ``loss.item()``
-        blocks (main.py:104) — and enqueues the next step while this step's backward and optimiser are still running."""
+        blocks (main.py:104) — and enqueues the next step while this step's backward and optimiser are still running.
+        Data-parallel (``group`` true): the five scalars are SUM-all-reduced on the side stream first (a 20-byte
+        collective that overlaps the backward), so the host reads GLOBAL losses / flags just as early, and the optimiser's
+        guard (``_dp_guard``) sees the flags of every rank."""
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.flat_params.device)
             self._ev_forward = torch.cuda.Event()
@@ -327,9 +330,21 @@ class PaceVaeV3(nn.Module):
         self._ev_forward.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._side_stream):
             self._side_stream.wait_event(self._ev_forward)
-            self._host_tail.copy_(self._step_tail, non_blocking=True)
+            src = self._step_losses
+            if group:
+                import torch.distributed as dist
+                if getattr(self, "_global_scalars", None) is None or self._global_scalars.device != src.device:
+                    self._global_scalars = torch.zeros(8, dtype=torch.float32, device=src.device)
+                    self._dp_guard = self._global_scalars[3:5]
+                self._global_scalars[:dl.LOSS_FLOATS].copy_(src)
+                dist.all_reduce(self._global_scalars, op=dist.ReduceOp.SUM, group=reduce_group)
+                src = self._global_scalars[:dl.LOSS_FLOATS]
+                self._host_tail[:dl.LOSS_FLOATS].copy_(src, non_blocking=True)
+                self._host_tail[7:8].copy_(self._step_tail[7:8], non_blocking=True)
+            else:
+                self._host_tail.copy_(self._step_tail, non_blocking=True)
             self._step_status.zero_()
-            self._early_scalars = self._step_losses.clone()     # the caller's recon / kld tensors (ready once _ev_tail is)
+            self._early_scalars = src.clone()     # the caller's recon / kld tensors (ready once _ev_tail is)
             self._ev_tail.record(self._side_stream)
         self._early_pending = True
 
@@ -444,7 +459,8 @@ class PaceVaeV3(nn.Module):
 
     # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
-                      packed: bool = False, defer_check: bool = False, early_read: bool = False) -> torch.Tensor:
+                      packed: bool = False, defer_check: bool = False, early_read: bool = False, group=None,
+                      reduce_group=None) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag, invalid-features flag]; nothing is synchronised."""
         eng = self._eng()
@@ -463,7 +479,7 @@ class PaceVaeV3(nn.Module):
         eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
         if early_read:
-            self._early_read()
+            self._early_read(group, reduce_group)
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta

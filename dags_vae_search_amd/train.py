@@ -38,7 +38,8 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
     Returns ``(loss_value: float, recon, kld)`` like the reference.  With the fused optimiser
     (``dags_vae_search_amd.optim.Adam``) the step runs without an autograd graph: forward+backward kernels write the
     flat gradient, ``group`` (a torch.distributed process group, or True for the default one) SUM-all-reduces it over
-    RCCL, and one fused kernel pair clips and applies Adam.  With any other optimiser the reference sequence runs on
+    RCCL, and one fused kernel pair clips and applies Adam.  Either way the call returns once the step's FORWARD is done
+    (where the reference's ``loss.item()`` returns) with the global loss; backward, all-reduce and optimiser are queued.  With any other optimiser the reference sequence runs on
     top of the autograd-wrapped kernels (parameters are ordinary leaf tensors with .grad)."""
     if not model.training:
         model.train()
@@ -46,21 +47,26 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
     if isinstance(optimizer, FusedAdam):
         if optimizer._model is None:
             optimizer.attach(model)
-        # feature validation is read with the losses below; single-GPU: the read-back starts right after the forward
-        losses = model.loss_and_grad(batch, defer_check=True, early_read=group is None)
-        if group is not None:
-            from .dist import allreduce_gradients
-            allreduce_gradients(model.flat_grads, losses, None if group is True else group)   # SUM, then clip (§8e)
+        # The step's only host sync is ONE small pinned read-back, taken right behind the FORWARD on a side stream
+        # (PaceVaeV3._early_read): feature-validation word + loss scalars + non-finite flag.  Data-parallel: the five scalars
+        # are all-reduced there too (a 20-byte collective overlapping the backward), the flat gradient is all-reduced on the
+        # main stream after the backward (ONE collective of P floats, SUM, then clip: SURVEY 8e).
+        dp = group is not None
+        pg = None if group is True else group
+        model.loss_and_grad(batch, defer_check=True, early_read=True, group=dp, reduce_group=pg)
+        guard = model._step_guard
+        if dp:
+            import torch.distributed as dist
+            dist.all_reduce(model.flat_grads, op=dist.ReduceOp.SUM, group=pg)
+            torch.cuda.current_stream().wait_event(model._ev_tail)     # the guard below reads the all-reduced flags
+            guard = model._dp_guard
         # A non-finite loss or an invalid batch must leave the weights and the moments alone: the reference raises inside
         # loss_direct (pace.py:97-98), before backward / clip / step (main.py:111-116).  The optimiser kernels are already
         # enqueued when the host learns about it, so they carry the two flags as a device-side guard and skip the update
         # (data-parallel: the flags were all-reduced with the losses, every rank skips and raises alike).
-        optimizer.step(max_grad_norm=max_grad_norm, guard=model._step_guard)
-        early = group is None
-        scalars = None if early else losses.clone()                 # `losses` is a reused device buffer
-        host, status = model.read_step()                            # the step's only host sync (one 32-byte copy)
-        if early:
-            scalars = model._early_scalars                          # cloned behind the forward on the side stream
+        optimizer.step(max_grad_norm=max_grad_norm, guard=guard)
+        host, status = model.read_step()                            # waits for the side stream's copy only
+        scalars = model._early_scalars                              # cloned behind the forward on the side stream
         recon, kld = scalars[1], scalars[2]
         if status != 0 or host[4] != 0.0:
             optimizer.step_skipped()

@@ -157,6 +157,15 @@ int dvs_decode(const dvs_shape* s, const float* params, int64_t n_params, void* 
 int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, const uint64_t* data, const uint8_t* card,
                    const uint64_t* parents, double* scratch, double* out, int32_t* status, void* stream);
 
+/* The relabelling step of BNLearnWrapper.score (src/problem/bn/bnlearn.py:34-45: graph vertex v stands for data-set variable
+ * labels[v]) on the device, from the row codec of dvs_build_records: labels device u8 [B][n_vars], preds device [B][n_vars]
+ * (u16, or u64 when preds_are_u64) -> parents device u64 [B][n_vars] in data-set variable indices, ready for dvs_bic_scores.
+ * status bit 5 (device int32, zeroed by the caller): the labels of a DAG are not a permutation of 0..n_vars-1 (the reference
+ * asserts, bnlearn.py:35); that DAG's masks are zero.  With dvs_encode this keeps the reference's predictor-data pipeline
+ * (experiments/01_bn_asia/main.py:268-303: encode -> BIC -> (mu, target) rows) on the device. */
+int dvs_bic_parent_masks(int32_t batch, int32_t n_vars, int32_t preds_are_u64, const uint8_t* labels, const void* preds,
+                         uint64_t* parents, int32_t* status, void* stream);
+
 /* Predictive mean of the reference's GP predictor (GPRegressionModel, src/predictors/gp.py:13-32:
  * ConstantMean + InducingPointKernel(ScaleKernel(RBFKernel())), evaluated as `model(test_x).mean`,
  * experiments/01_bn_asia/main.py:367-368):  out[b] = constant + outputscale * sum_m alpha[m] exp(-|x_b - z_m|^2 / (2 l^2)).
@@ -166,6 +175,22 @@ int dvs_bic_scores(int32_t batch, int32_t n_vars, int32_t n_samples, const uint6
 int dvs_gp_predict(int32_t batch, int32_t n_inducing, int32_t dim, const float* x, const float* inducing,
                    const double* alpha, double outputscale, double lengthscale, double constant, double* out,
                    void* stream);
+
+/* Hyper-parameter training of the same predictor (reference loop: src/predictors/gp.py:55-81 = experiments/01_bn_asia/
+ * main.py:329-365, Adam lr 0.01 on -ExactMarginalLogLikelihood(likelihood, model) of the SGPR model): the two kernel-specific
+ * steps of one iteration.  The M x M / M x n Cholesky factorisations between them are dense library calls of the host side
+ * (dags_vae_search_amd/predictor.py), the parameter update is dvs_clip_adam over the flat [inducing points | 4 raw scalars].
+ * dvs_gp_kernel: K [na][nb] (device f64) = outputscale * exp(-|xa_a - xb_b|^2 / (2 lengthscale^2)); xa [na][dim], xb [nb][dim]
+ * device f32, dim <= 32.
+ * dvs_gp_kernel_backward: G = d objective / d K [na][nb] (device f64) -> dxa [na][dim] (device f64, overwritten):
+ * sum_b G'_ab K_ab (xb_b - xa_a) / l^2 with G' = G + G^T when `symmetric` (xa and xb are the same point set, K_uu), else
+ * G' = G; row_sums [na][2] (device f64, overwritten): per-row partial sums of d/d lengthscale (sum_b G K d^2 / l^3) and
+ * d/d outputscale (sum_b G K / o); the caller adds the rows.  Fixed summation order (bitwise reproducible). */
+int dvs_gp_kernel(int32_t na, int32_t nb, int32_t dim, const float* xa, const float* xb, double outputscale,
+                  double lengthscale, double* K, void* stream);
+int dvs_gp_kernel_backward(int32_t na, int32_t nb, int32_t dim, int32_t symmetric, const float* xa, const float* xb,
+                           double outputscale, double lengthscale, const double* G, double* dxa, double* row_sums,
+                           void* stream);
 
 /* Optional per-kernel timing for the benchmark's roofline leg: while enabled, every kernel launch is bracketed by
  * HIP events recorded on its own stream; dvs_profile_collect waits for them and returns, per kernel name, the

@@ -46,3 +46,65 @@ def fit_alpha(train_x, train_y, Z, h, jitter=1e-6):
 
 def predict_mean(x, Z, alpha, h):
     return h["constant"] + kernel(np.asarray(x, np.float64), np.asarray(Z, np.float64), h["outputscale"], h["lengthscale"]) @ alpha
+
+
+# ---- hyper-parameter training (reference: src/predictors/gp.py:55-81, experiments/01_bn_asia/main.py:315-393) ----------
+# What the reference's loop optimises, restated from gpytorch 1.13's published algorithm (source not under
+# /root/reference; call sites gp.py:21-26, 62, 73-77): ExactMarginalLogLikelihood of an ExactGP whose kernel is
+# InducingPointKernel = the collapsed SGPR bound of Titsias (2009), divided by the number of training points,
+#     -loss * n = log N(y | c, Q_ff + s^2 I) - (1 / 2 s^2) sum_i (k_ii - q_ii),      Q_ff = K_fu K_uu^-1 K_uf,
+# (ExactMarginalLogLikelihood subtracts the kernel's InducingPointKernelAddedLossTerm = the trace term), minimised by
+# Adam(lr 0.01, torch defaults) over {raw_noise, raw_constant, raw_outputscale, raw_lengthscale, inducing_points}, all
+# float32 in the reference and started from gpytorch's defaults (raw values 0 -> softplus(0) = 0.693; noise has a
+# GreaterThan(1e-4) constraint; constant 0; inducing points = train_x[:500]).  Computed here in float64 through
+# Cholesky factors (Woodbury), with autograd supplying the gradient: this is the checker for the device implementation's
+# hand-derived gradient (dags_vae_search_amd/predictor.py).
+def vfe_loss_torch(raw, Z, X, y, jitter=1e-6):
+    """raw: dict of 0-d float64 tensors raw_noise, raw_constant, raw_outputscale, raw_lengthscale; Z [M, D]; X [n, D];
+    y [n].  Returns the loss the reference's loop prints (-mll)."""
+    import torch
+    import torch.nn.functional as F
+    noise = F.softplus(raw["raw_noise"]) + 1e-4
+    o = F.softplus(raw["raw_outputscale"])
+    l = F.softplus(raw["raw_lengthscale"])
+    c = raw["raw_constant"]
+
+    def k(a, b):
+        d2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        return o * torch.exp(-0.5 * d2.clamp_min(0.0) / (l * l))
+    n, M = X.shape[0], Z.shape[0]
+    Kuu = k(Z, Z) + jitter * torch.eye(M, dtype=Z.dtype)
+    Kuf = k(Z, X)
+    L = torch.linalg.cholesky(Kuu)
+    A = torch.linalg.solve_triangular(L, Kuf, upper=False) / noise.sqrt()
+    Bm = torch.eye(M, dtype=Z.dtype) + A @ A.T
+    LB = torch.linalg.cholesky(Bm)
+    r = y - c
+    cv = torch.linalg.solve_triangular(LB, (A @ r)[:, None], upper=False)[:, 0] / noise.sqrt()
+    logdet = n * torch.log(noise) + 2.0 * torch.log(torch.diagonal(LB)).sum()
+    quad = (r * r).sum() / noise - (cv * cv).sum()
+    logp = -0.5 * n * np.log(2.0 * np.pi) - 0.5 * logdet - 0.5 * quad
+    trace = 0.5 * (n * o / noise - (A * A).sum())
+    return -(logp - trace) / n
+
+
+def train_torch(X, y, M=500, iterations=1000, lr=0.01, log_every=0, dtype=None):
+    """The reference's loop on the CPU (float64 maths, float32 parameters like the reference's)."""
+    import torch
+    dtype = dtype or torch.float64
+    X64, y64 = torch.as_tensor(X, dtype=dtype), torch.as_tensor(y, dtype=dtype)
+    P = {k: torch.zeros((), dtype=torch.float32, requires_grad=True) for k in
+         ("raw_noise", "raw_constant", "raw_outputscale", "raw_lengthscale")}
+    Z = torch.as_tensor(X[:M], dtype=torch.float32).clone().requires_grad_(True)
+    opt = torch.optim.Adam(list(P.values()) + [Z], lr=lr)
+    hist = []
+    for it in range(iterations):
+        opt.zero_grad()
+        loss = vfe_loss_torch({k: v.to(dtype) for k, v in P.items()}, Z.to(dtype), X64, y64)
+        loss.backward()
+        opt.step()
+        if log_every and (it + 1) % log_every == 0:
+            hist.append((it + 1, float(loss)))
+    out = {k: v.detach().numpy().copy() for k, v in P.items()}
+    out["inducing_points"] = Z.detach().numpy().copy()
+    return out, hist

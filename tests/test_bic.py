@@ -62,3 +62,28 @@ def test_emu_bic_kernel_matches_oracle(name, n, count):
     assert np.abs(out - ref).max() < 1e-8
     assert lib.dvs_bic_scores(count, 49, data.shape[0], ptr(packed), ptr(card), ptr(masks), ptr(scratch), ptr(out),
                               ptr(status), None) != 0
+
+
+@pytest.mark.parametrize("n,count", [(8, 40), (11, 20), (37, 6)])
+def test_emu_parent_masks_from_the_row_codec(n, count):
+    """dvs_bic_parent_masks (relabelling of bnlearn.py:34-45 on the row codec) == the host construction used above; a DAG
+    whose labels are not a permutation raises status bit 5 and gets zero masks."""
+    from dags_vae_search_amd.records import encode_graphs
+    from tests.emu.harness import emu, ptr
+    graphs = ofeat.synthetic_dags(n, n, count, seed=3, density_limit=0.4 if n <= 13 else 0.2)
+    cb = encode_graphs(graphs, n)
+    lab = np.ascontiguousarray(cb.labels.numpy())
+    pr = np.ascontiguousarray(cb.preds.numpy())
+    want = np.zeros((count, n), np.uint64)
+    for b, (l, edges) in enumerate(graphs):
+        for u, v in edges:
+            want[b, l[v]] |= np.uint64(1) << np.uint64(l[u])
+    got = np.full((count, n), 0xFFFF, np.uint64)
+    status = np.zeros(1, np.int32)
+    lib = emu()
+    assert lib.dvs_bic_parent_masks(count, n, 1 if n > 13 else 0, ptr(lab), ptr(pr), ptr(got), ptr(status), None) == 0
+    assert status[0] == 0 and np.array_equal(got, want)
+    lab[1, 0] = lab[1, 1]                       # duplicate label: not a permutation
+    assert lib.dvs_bic_parent_masks(count, n, 1 if n > 13 else 0, ptr(lab), ptr(pr), ptr(got), ptr(status), None) == 0
+    assert status[0] == 32 and not got[1].any() and np.array_equal(got[2:], want[2:])
+    assert lib.dvs_bic_parent_masks(count, 20, 0, ptr(lab), ptr(pr), ptr(got), ptr(status), None) != 0     # u16 rows, n > 16

@@ -64,3 +64,38 @@ def test_bic_sort_path_large_parent_sets():
     got = ev.score_batch(graphs)
     for g, val in zip(graphs, got):
         assert val == pytest.approx(obic.bic(data, card, g.labels, g.edges), abs=1e-7)
+
+
+def test_predictor_data_pipeline_reproduces_the_references_1408_rows(tmp_path):
+    """the mirror of prepare_predictor_data (experiments/01_bn_asia/main.py:268-303; utils.py:15-59) —
+    encode -> BIC -> (vector, target) rows, all on the device — against BOTH columns of the data set the reference itself
+    wrote with checkpoint 110 and Rscript (experiments/01_bn_asia/predictor_dataset, 1 408 rows = 22 batches of 64; graphs
+    re-associated by tests/golden/gen_predictor_graphs.py)."""
+    import pyarrow.parquet as pq
+    from dags_vae_search_amd import BNLearnWrapper, LabeledGraph, PaceVaeV3, prepare_predictor_data
+    fix = load_npz("asia_predictor.npz")
+    ck = load_npz("asia_ckpt110.npz")
+    graphs = [LabeledGraph(list(l), list(e)) for l, e in graphs_from(load_npz("asia_predictor_graphs.npz"), 8)]
+    assert len(graphs) == 1408
+    model = PaceVaeV3(8, 8, 32, 8, 3, 64, 32, 32, 0.15)
+    model.load_state_dict({k: torch.from_numpy(ck[k]) for k in ck.files})
+    model = model.to("cuda:0")
+    ev = BNLearnWrapper("asia", "bic", data=load_npz("bn_asia_data.npz")["data"])
+    vec, tgt = prepare_predictor_data(model, graphs, ev, batch_size=64, output_dir=str(tmp_path / "predictor_dataset"))
+    assert vec.is_cuda and tgt.is_cuda and vec.shape == (1408, 32) and tgt.dtype == torch.float64
+    assert np.abs(vec.cpu().numpy() - fix["x"]).max() < 1e-5           # reference-written vectors (fp32)
+    assert np.abs(tgt.cpu().numpy() - fix["y"]).max() < 1e-6           # reference-written targets (Rscript bnlearn)
+    parts = list((tmp_path / "predictor_dataset").glob("part-*.parquet"))
+    assert len(parts) == 22
+    t = pq.read_table(tmp_path / "predictor_dataset" / "part-3.parquet").to_pylist()
+    assert len(t) == 64 and set(t[0]) == {"vector", "target"}
+    assert np.allclose(np.asarray(t[5]["vector"], np.float32), fix["x"][3 * 64 + 5], atol=1e-5)
+    assert t[5]["target"] == pytest.approx(float(fix["y"][3 * 64 + 5]), abs=1e-6)
+    # a plain callable evaluator (the reference's signature) gives the same targets
+    _, tgt2 = prepare_predictor_data(model, graphs[:64], ev.score, batch_size=64)
+    assert np.abs(tgt2.cpu().numpy() - fix["y"][:64]).max() < 1e-6
+    with pytest.raises(AssertionError):
+        from dags_vae_search_amd import encode_graphs
+        bad = encode_graphs(graphs[:4], 8)
+        bad.labels[0, 0] = bad.labels[0, 1]
+        ev.score_compact(bad.to("cuda:0"))

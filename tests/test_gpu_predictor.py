@@ -30,3 +30,43 @@ def test_gp_predictor_matches_oracle_and_shipped_behaviour():
     assert big.shape == (4096,) and torch.isfinite(big).all()
     with pytest.raises(AssertionError):
         model.predict(torch.randn(4, 16))
+
+
+def test_gp_hyperparameter_training_follows_the_reference_loop():
+    """SURVEY §8f-4 / VERDICT r1: SGPR hyper-parameter training on the device (gp.py:55-81, main.py:329-365).  PARITY UNPINNED
+    against gpytorch (absent).  (1) 60 full-size iterations (n = 1126, M = 500) against the oracle's restatement of the loop
+    (autograd gradient, torch.optim.Adam): same losses and parameters.  (2) 2000 iterations land on the oracle's recorded
+    trajectory (CPU run of oracle.gp.train_torch, float64 maths: raw noise 6.348, outputscale 5.263, lengthscale 2.042,
+    constant -8.791 at iteration 2000; by iteration ~9000 noise / outputscale / constant pass through the reference's SHIPPED
+    values 26.0 / 19.2 / -49.5 (oracle at 8000: 21.0 / 17.3 / -46.4, at 10000: 28.6 / 23.6 / -62.4), the lengthscale does not
+    (3.2 vs 8.7; float32 Cholesky jitter on gpytorch's near-rank-one K_uu is the suspected difference) — DESIGN.md §10).
+    (3) the trained model predicts like the shipped one: test MAE = the constant predictor's (reference data carry no more)."""
+    from dags_vae_search_amd.predictor import GPRegressionModel
+    fix = load_npz("asia_predictor.npz")
+    x, y = torch.from_numpy(fix["x"]), torch.from_numpy(fix["y"])
+    ntr = int(np.floor(0.8 * len(x)))
+    model = GPRegressionModel(x[:ntr], y[:ntr])
+    hist = model.train_hyperparameters(iterations=60, lr=0.01, log_every=20, log=lambda *_: None)
+    ref, rhist = ogp.train_torch(fix["x"][:ntr], fix["y"][:ntr], M=500, iterations=60, lr=0.01, log_every=20)
+    assert [h[0] for h in hist] == [20, 40, 60]
+    assert all(abs(a[1] - b[1]) < 1e-5 * abs(b[1]) for a, b in zip(hist, rhist)), (hist, rhist)
+    sd = model.state_dict()
+    got = {"raw_noise": sd["likelihood.noise_covar.raw_noise"], "raw_constant": sd["mean_module.raw_constant"],
+           "raw_outputscale": sd["base_covar_module.raw_outputscale"],
+           "raw_lengthscale": sd["base_covar_module.base_kernel.raw_lengthscale"]}
+    for k, v in got.items():
+        assert abs(float(v.reshape(-1)[0]) - float(ref[k])) < 2e-3, (k, float(v.reshape(-1)[0]), float(ref[k]))
+    assert float((sd["covar_module.inducing_points"] - torch.from_numpy(ref["inducing_points"])).abs().max()) < 5e-3
+    assert sd["covar_module.inducing_points"].shape == (500, 32) and sd["likelihood.noise_covar.raw_noise"].shape == (1,)
+    import time
+    t0 = time.perf_counter()
+    hist = model.train_hyperparameters(iterations=2000, lr=0.01, log_every=500, log=lambda *_: None)
+    print(f"\nGP training: {(time.perf_counter() - t0) / 2000 * 1e3:.2f} ms per iteration (n = {ntr}, M = 500)")
+    assert hist[-1][1] < hist[0][1] < 3.0e5
+    sd = model.state_dict()
+    for key, want in (("likelihood.noise_covar.raw_noise", 6.3476), ("base_covar_module.raw_outputscale", 5.2632),
+                      ("base_covar_module.base_kernel.raw_lengthscale", 2.0416), ("mean_module.raw_constant", -8.7909)):
+        assert abs(float(sd[key].reshape(-1)[0]) - want) < 0.02 * abs(want), (key, float(sd[key].reshape(-1)[0]), want)
+    pred = model.predict(x[ntr:]).cpu().numpy()
+    mae = float(np.abs(pred - fix["y"][ntr:]).mean())
+    assert abs(mae - 687.35) < 3.0, mae                 # oracle at 2000 iterations: 687.35; shipped model: 686.1

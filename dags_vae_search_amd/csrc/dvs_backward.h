@@ -7,6 +7,7 @@
 // no float atomics on HBM, bitwise reproducible gradients.
 #pragma once
 #include "dvs_kernels.h"
+#include "dvs_stage.h"
 
 struct FfnBwdArgs {
     DvsDims dims;
@@ -101,7 +102,9 @@ struct BwdPhase {
 struct BwdStackArgs {
     int nphase, pad;
     BwdPhase ph[DVS_STACK_PHASES];
+    DvsStagePlan plan[DVS_STACK_PHASES];     // filled by dvs_launch_bwd_stack (dvs_stage.h): what each phase keeps in LDS
 };
+static_assert(sizeof(BwdStackArgs) <= 4096, "kernel argument block limit");
 void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 decoder, 1 encoder (profile names)
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st);
@@ -262,28 +265,28 @@ __device__ __forceinline__ float dvs_colsum(const float* slot, const Lane& L) {
     for (int rr = 0; rr < 16; ++rr) s += slot[rr * DVS_LD + L.lane];
     return s;
 }
-// Add the two groups' partial dW (rows 16*(wave&3).. each) and write the 64x64 result to the slab.  buf: 4096 floats of
-// LDS.  Contains workgroup barriers: call from all 8 waves.
-__device__ __forceinline__ void dvs_coop_store(float* buf, float* dst, const f4 (&acc)[4], const Lane& L, bool rperm = false,
-                                               bool cperm = false, int ld_dst = 64) {
+// Add the two groups' partial dW (rows 16*(wave&3).. each) and write the 64x64 result to the slab, in two halves around ONE
+// workgroup barrier shared by all matrices (and the vector sums) of a phase's epilogue: waves 0-3 stage every matrix in its
+// own 4096-float LDS buffer, barrier, waves 4-7 add theirs and store.  (Round 1 paid two barriers per matrix.)
+__device__ __forceinline__ void dvs_coop_stage(float* buf, const f4 (&acc)[4], const Lane& L) {
+    if (L.wave >= 4) return;
     const int ot = L.wave & 3;
-    if (L.wave < 4) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) buf[(16 * ot + 4 * L.g + reg) * 64 + 16 * it + L.r] = acc[it][reg];
-    }
-    __syncthreads();
-    if (L.wave >= 4) {
+        for (int reg = 0; reg < 4; ++reg) buf[(16 * ot + 4 * L.g + reg) * 64 + 16 * it + L.r] = acc[it][reg];
+}
+__device__ __forceinline__ void dvs_coop_flush(const float* buf, float* dst, const f4 (&acc)[4], const Lane& L, bool rperm = false,
+                                               bool cperm = false, int ld_dst = 64) {
+    if (L.wave < 4) return;
+    const int ot = L.wave & 3;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = 16 * ot + 4 * L.g + reg, col = 16 * it + L.r;
-                dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = acc[it][reg] + buf[row * 64 + col];
-            }
-    }
-    __syncthreads();
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * ot + 4 * L.g + reg, col = 16 * it + L.r;
+            dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = acc[it][reg] + buf[row * 64 + col];
+        }
 }
 // LayerNorm backward without the parameter-gradient accumulation (done by column sums of parked tiles)
 __device__ __forceinline__ void dvs_ln_bwd_core(f4 (&dx)[4], const f4 (&xhat)[4], float rstd, const float* lg, const Lane& L) {

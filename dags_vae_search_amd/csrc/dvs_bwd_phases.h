@@ -13,10 +13,13 @@ static size_t projb_lds_bytes(int nproj) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// FFN sublayer backward (autograd of pace.py:62-65 / 151-153).  Recomputes h = drop(relu(W1 x + b1)) from the saved
-// pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
-// ---------------------------------------------------------------------------------------------------------
+#include "dvs_stage.h"
+
+#ifdef DVS_STAMPS
+DVS_STAMP_DECL(dvs_stamps_bwd);
+#endif
+
+// ---- LDS layouts of the three phase kinds ----------------------------------------------------------------------------
 struct FfnBLds {
     // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as the bf16x6 triple k_ffn_fwd uses: the hidden is
     // recomputed with the forward's own instruction sequence, because its sign must reproduce the forward's ReLU mask.
@@ -24,7 +27,7 @@ struct FfnBLds {
     dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl, *W1x6;
     float *b1, *b2, *lg, *lb, *og, *ob, *slots;
 };
-__device__ __forceinline__ FfnBLds ffnb_lds(char* smem) {
+DVS_HD inline FfnBLds ffnb_lds(char* smem) {
     FfnBLds l;
     l.W2Th = (dvs_bf16*)smem;
     l.W2Tl = l.W2Th + 64 * DVS_LDB;
@@ -44,28 +47,132 @@ static size_t ffnb_lds_bytes() {
     return 7 * 64 * DVS_LDB * sizeof(dvs_bf16) + (6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
 }
 
+struct AttnBLds {
+    float *inb, *outb, *lg, *lb, *slots, *stats;
+    // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
+    // ~1e-5 perturbation stays a ~1e-5 perturbation of the gradient; the FFN's hidden, whose SIGN is a mask, is recomputed
+    // with the forward's own bf16x6 sequence instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
+    dvs_bf16 *Winh, *Winl, *WoTh, *WoTl;
+    int* gcount;
+};
+DVS_HD inline AttnBLds attnb_lds(char* smem) {
+    AttnBLds l;
+    l.Winh = (dvs_bf16*)smem;
+    l.Winl = l.Winh + 192 * DVS_LDB;
+    l.WoTh = l.Winl + 192 * DVS_LDB;
+    l.WoTl = l.WoTh + 64 * DVS_LDB;
+    l.inb = (float*)(l.WoTl + 64 * DVS_LDB);
+    l.outb = l.inb + 192;
+    l.lg = l.outb + 64;
+    l.lb = l.lg + 64;
+    l.slots = l.lb + 64;                       // per wave: A (d y, row-major) and B (transpose scratch, then O)
+    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
+    l.gcount = (int*)(l.stats + 8 * 128);
+    return l;
+}
+static size_t attnb_lds_floats() {
+    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
+}
+
+
+struct ProjBLds {
+    dvs_bf16* WT;                // [NPROJ][hi | lo][64][LDB]
+    float *lg, *lb;
+    dvs_bf16* slots;             // per wave 3 tiles [hi | lo]: A0, A1 (alternating dY) and B (X)
+    int* gcount;
+};
+DVS_HD inline ProjBLds projb_lds(char* smem, int nproj) {
+    ProjBLds l;
+    l.WT = (dvs_bf16*)smem;
+    l.lg = (float*)(l.WT + nproj * 2 * DVS_IMG64);
+    l.lb = l.lg + 64;
+    l.slots = (dvs_bf16*)(l.lb + 64);
+    l.gcount = (int*)(l.slots + 8 * DVS_PROJB_SLOT);
+    return l;
+}
+
+// ---- staging plans (dvs_stage.h): what each phase kind keeps in LDS --------------------------------------------------
+inline void ffnb_plan(DvsStagePlan& p, const FfnBwdArgs& a, char* smem) {
+    const FfnBLds l = ffnb_lds(smem);
+    dvs_plan_clear(p);
+    dvs_plan_seg(p, smem, l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
+    dvs_plan_seg(p, smem, l.W1x6, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(3 * DVS_IMG64));
+    dvs_plan_vec(p, smem, l.b1, a.l1_b, 64);
+    dvs_plan_vec(p, smem, l.b2, a.l2_b, 64);
+    dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.og, a.own.g, a.own_pre ? 64 : 0);
+    dvs_plan_vec(p, smem, l.ob, a.own.b, a.own_pre ? 64 : 0);
+    p.zero_int = (int)(((const char*)(l.slots + 8 * 2 * DVS_SCR) - smem) >> 2);
+    dvs_plan_seal(p);
+}
+inline void attnb_plan(DvsStagePlan& p, const AttnBwdArgs& a, char* smem) {
+    const AttnBLds l = attnb_lds(smem);
+    dvs_plan_clear(p);
+    dvs_plan_seg(p, smem, l.Winh, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, 2 * 192 * DVS_LDB);   // parts hi, mid of the x6 triple = the x3 pair
+    dvs_plan_seg(p, smem, l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));
+    dvs_plan_vec(p, smem, l.inb, a.in_b, 192, true);
+    dvs_plan_vec(p, smem, l.outb, a.out_b, 64);
+    dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
+    p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
+    dvs_plan_seal(p);
+}
+inline void projb_plan(DvsStagePlan& p, const ProjBwdArgs& a, int nproj, char* smem) {
+    const ProjBLds l = projb_lds(smem, nproj);
+    dvs_plan_clear(p);
+    dvs_plan_seg(p, smem, l.WT, a.wimg, (int)(nproj * 2 * DVS_IMG64));
+    dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
+    p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
+    dvs_plan_seal(p);
+}
+inline void dvs_bwd_plan(DvsStagePlan& p, const BwdPhase& ph, char* smem) {
+    switch (ph.kind) {
+        case DVS_PH_FFN: ffnb_plan(p, ph.u.f, smem); break;
+        case DVS_PH_ATTN: attnb_plan(p, ph.u.a, smem); break;
+        case DVS_PH_PROJ1: projb_plan(p, ph.u.p, 1, smem); break;
+        case DVS_PH_PROJ2: projb_plan(p, ph.u.p, 2, smem); break;
+        default: projb_plan(p, ph.u.p, 3, smem); break;
+    }
+}
+// Tail of every phase: the plan of the phase that follows in the chained launch (null: none) is fetched while this one ends.
+struct DvsBwdTail {
+    DvsPrefetch<DVS_PF_BWD_TAIL> pf;
+};
+template <class PP>
+__device__ __forceinline__ void dvs_tail_issue(DvsBwdTail& t, PP next, bool has_next) {
+    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_issue(t.pf, next, dvs_tid(), DVS_PF_THREADS);
+}
+// call after the last LDS access of the epilogue, with a workgroup barrier in between; the caller's next barrier publishes it
+template <class PP>
+__device__ __forceinline__ void dvs_tail_commit(const DvsBwdTail& t, PP next, bool has_next, char* smem) {
+    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_commit(t.pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FFN sublayer backward (autograd of pace.py:62-65 / 151-153).  Recomputes h = drop(relu(W1 x + b1)) from the saved
+// pre-sum of the producing sublayer; all four products (dW2, dh, dW1, dx) are MFMA chains on registers.
+// ---------------------------------------------------------------------------------------------------------
 // 8 waves per workgroup, one DAG per wave per iteration; weight gradients are accumulated cooperatively
 // (dvs_coop_dw_bf): ~150 registers per lane, two waves per SIMD, so one wave's VALU phases overlap the other's MFMAs.
 // The gradient products (d hidden, d x, and the weight gradients) run on the bf16 matrix pipe as bf16x3: gradient
 // parity is bounded at 2e-3 of the tensor maximum (tests), two orders of magnitude above their ~1e-5 error, whereas
 // the forward keeps fp32-accurate bf16x6 products for the 1e-4 ELBO contract and the hidden is recomputed with them.
-__device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* smem) {
+// mine / stage_mine: this phase's staging plan; stage_mine is false when the previous phase of the chain already put it into
+// LDS (and a barrier has passed since).  next / has_next: the plan of the phase that follows, fetched in this phase's tail
+// (dvs_stage.h).  PP: plan pointer type (dvs_stage.h: plain, or into the kernel-argument segment).
+template <class PP>
+__device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
+                                                  bool has_next) {
     const FfnBLds l = ffnb_lds(smem);
-    dvs_copy_image(l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
-    dvs_copy_image(l.W1x6, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(3 * DVS_IMG64));
-    dvs_stage_vector(l.b1, a.l1_b, 64);
-    dvs_stage_vector(l.b2, a.l2_b, 64);
-    if (a.ln.stats) {
-        dvs_stage_vector(l.lg, a.ln.g, 64);
-        dvs_stage_vector(l.lb, a.ln.b, 64);
+    DVS_STAMP(dvs_stamps_bwd, mine, 0);
+    if (stage_mine) {
+        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        __syncthreads();
     }
-    if (a.own_pre) {
-        dvs_stage_vector(l.og, a.own.g, 64);
-        dvs_stage_vector(l.ob, a.own.b, 64);
-    }
+    DVS_STAMP(dvs_stamps_bwd, mine, 1);
     int* gcount = (int*)(l.slots + 8 * 2 * DVS_SCR);
-    if (dvs_tid() < 2) gcount[dvs_tid()] = 0;
-    __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int B = a.dims.B * a.dims.NT;                    // tiles (dvs_tile_of): the sublayer is token-local
@@ -157,11 +264,18 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         }
         if (live) dvs_store_tile(a.gout, dag, dx, L);
     }
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    DvsBwdTail tail;
+    dvs_tail_issue(tail, next, has_next);
+    DVS_STAMP(dvs_stamps_bwd, mine, 3);
+    dvs_lds_barrier();
+    DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
-    dvs_coop_store((float*)smem, slab + a.o_l1_w, aW1, L);
-    dvs_coop_store((float*)smem, slab + a.o_l2_w, aW2, L);
-    float* red = (float*)smem;                        // [8 waves][6][64]
+    float* const buf1 = (float*)smem;                  // one 64 x 64 staging buffer per matrix, then the vector sums
+    float* const buf2 = buf1 + 4096;
+    float* red = buf2 + 4096;                         // [8 waves][6][64]
+    dvs_coop_stage(buf1, aW1, L);
+    dvs_coop_stage(buf2, aW2, L);
     red[(L.wave * 6 + 0) * 64 + L.lane] = 0.f;
     red[(L.wave * 6 + 1) * 64 + L.lane] = 0.f;
     red[(L.wave * 6 + 2) * 64 + L.lane] = vgam;
@@ -176,7 +290,9 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
             red[(L.wave * 6 + 1) * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = ab2[reg];
         }
     }
-    __syncthreads();
+    dvs_lds_barrier();
+    dvs_coop_flush(buf1, slab + a.o_l1_w, aW1, L);
+    dvs_coop_flush(buf2, slab + a.o_l2_w, aW2, L);
     if (dvs_tid() < 6 * 64) {
         const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
         float s = 0.f;
@@ -184,6 +300,10 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         const int64_t off = k == 0 ? a.o_l1_b : k == 1 ? a.o_l2_b : k == 2 ? a.o_ln_g : k == 3 ? a.o_ln_b : k == 4 ? a.o_own_g : a.o_own_b;
         if (off >= 0) slab[off + f] = s;
     }
+    DVS_STAMP(dvs_stamps_bwd, mine, 5);
+    dvs_lds_barrier();
+    dvs_tail_commit(tail, next, has_next, smem);
+    DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -194,24 +314,25 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
 // 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw_bf):
 // per wave 16 accumulator registers per projection, ~130 VGPRs, two waves per SIMD.  LDS slots per wave: X (kept for
 // all projections of the DAG) and two alternating dY slots, so one group barrier per projection + one per DAG.
-template <int NPROJ>
-__device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* smem) {
+template <int NPROJ, class PP>
+__device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
+                                                   bool has_next) {
     // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
     // of the forward depends on it), so it runs on the bf16 matrix pipe.  So do the weight gradients dW_p = dY_p^T X: the
     // tiles are parked as bf16 hi / lo images and read back transposed (dvs_coop_dw_bf); the bias gradients ride along as
     // products with a ones fragment.
-    dvs_bf16* WT = (dvs_bf16*)smem;                // [NPROJ][hi | lo][64][LDB]
-    float* lg = (float*)(WT + NPROJ * 2 * DVS_IMG64);
-    float* lb = lg + 64;
-    dvs_bf16* slots = (dvs_bf16*)(lb + 64);        // per wave 3 tiles [hi | lo]: A0, A1 (alternating dY) and B (X)
-    int* gcount = (int*)(slots + 8 * DVS_PROJB_SLOT);
-    dvs_copy_image(WT, (const dvs_bf16*)a.wimg, (int)(NPROJ * 2 * DVS_IMG64));
-    if (a.ln.stats) {
-        dvs_stage_vector(lg, a.ln.g, 64);
-        dvs_stage_vector(lb, a.ln.b, 64);
+    const ProjBLds pl = projb_lds(smem, NPROJ);
+    dvs_bf16* WT = pl.WT;
+    float* lg = pl.lg;
+    float* lb = pl.lb;
+    dvs_bf16* slots = pl.slots;
+    int* gcount = pl.gcount;
+    DVS_STAMP(dvs_stamps_bwd, mine, 0);
+    if (stage_mine) {
+        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        __syncthreads();
     }
-    if (dvs_tid() < 2) gcount[dvs_tid()] = 0;
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_bwd, mine, 1);
     const Lane L = dvs_lane();
     const int B = a.dims.B * a.dims.NT;              // tiles
     dvs_bf16* myA0 = slots + L.wave * DVS_PROJB_SLOT;
@@ -277,12 +398,18 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
             dvs_store_tile(a.gout, dag, dx, L);
         }
     }
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    DvsBwdTail tail;
+    dvs_tail_issue(tail, next, has_next);
+    DVS_STAMP(dvs_stamps_bwd, mine, 3);
+    dvs_lds_barrier();
+    DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
     const bool so = a.slot_order != 0;
+    float* const bufs = (float*)smem;                  // NPROJ staging buffers of 4096 floats, then the vector sums
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) dvs_coop_store((float*)smem, slab + a.o_w + 4096 * p, aW[p], L, so, false);
-    float* red = (float*)smem;                        // [8 waves][NPROJ + 2][64]
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_stage(bufs + 4096 * p, aW[p], L);
+    float* red = bufs + 4096 * NPROJ;                 // [8 waves][NPROJ + 2][64]
     // bias gradients: wave (group, ot) holds the sums of features 16*ot + 4g + reg (every column r the same)
 #pragma unroll
     for (int p = 0; p < NPROJ; ++p) red[(L.wave * (NPROJ + 2) + p) * 64 + L.lane] = 0.f;
@@ -295,7 +422,9 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) red[(L.wave * (NPROJ + 2) + p) * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = ab[p][reg];
     }
-    __syncthreads();
+    dvs_lds_barrier();
+#pragma unroll
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_flush(bufs + 4096 * p, slab + a.o_w + 4096 * p, aW[p], L, so, false);
     if (dvs_tid() < (NPROJ + 2) * 64) {
         const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
         float s = 0.f;
@@ -303,6 +432,10 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
         if (k < NPROJ) slab[a.o_b + 64 * k + (so ? dvs_pi(f) : f)] = s;
         else if (a.o_ln_g >= 0) slab[(k == NPROJ ? a.o_ln_g : a.o_ln_b) + f] = s;
     }
+    DVS_STAMP(dvs_stamps_bwd, mine, 5);
+    dvs_lds_barrier();
+    dvs_tail_commit(tail, next, has_next, smem);
+    DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -315,33 +448,6 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
 //   "S":  P  [i=4g+reg][j=r]  -> recomputed from the T statistics (3 shuffles), dP, dS -> dk^T, dv^T
 // q,k (T-layout) feed the score products directly; their N-layout copies (for dq/dk), v^T and dO (N) come from
 // per-wave LDS transposes.
-
-struct AttnBLds {
-    float *inb, *outb, *lg, *lb, *slots, *stats;
-    // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
-    // ~1e-5 perturbation stays a ~1e-5 perturbation of the gradient; the FFN's hidden, whose SIGN is a mask, is recomputed
-    // with the forward's own bf16x6 sequence instead) and Wo^T (dO^T = Wo^T dy^T, a pure gradient product)
-    dvs_bf16 *Winh, *Winl, *WoTh, *WoTl;
-    int* gcount;
-};
-__device__ __forceinline__ AttnBLds attnb_lds(char* smem) {
-    AttnBLds l;
-    l.Winh = (dvs_bf16*)smem;
-    l.Winl = l.Winh + 192 * DVS_LDB;
-    l.WoTh = l.Winl + 192 * DVS_LDB;
-    l.WoTl = l.WoTh + 64 * DVS_LDB;
-    l.inb = (float*)(l.WoTl + 64 * DVS_LDB);
-    l.outb = l.inb + 192;
-    l.lg = l.outb + 64;
-    l.lb = l.lg + 64;
-    l.slots = l.lb + 64;                       // per wave: A (d y, row-major) and B (transpose scratch, then O)
-    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
-    l.gcount = (int*)(l.stats + 8 * 128);
-    return l;
-}
-static size_t attnb_lds_floats() {
-    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
-}
 
 // Dropout keep-bits of the attention probabilities of one DAG, all 8 heads.  T orientation: lane (r, g) owns the elements
 // (query i = r, key j = 4g + reg) -> bit 4h + reg of `T`, drawn exactly like the forward does (element index
@@ -399,18 +505,16 @@ __device__ __forceinline__ f4 mask_S(const ProbMask& m, int h, const DvsDrop& D)
 // 8 waves per workgroup in two independent groups of four (dvs_backward.h); one DAG per wave per iteration.  The
 // out-projection gradient is accumulated cooperatively from the parked d y and O tiles, d q / d k / d v tiles are stored
 // as soon as their head pair is finished, so a wave stays within 256 registers and two waves share each SIMD.
-__device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* smem) {
+template <class PP>
+__device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
+                                                   bool has_next) {
     const AttnBLds l = attnb_lds(smem);
-    dvs_copy_image(l.Winh, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, 2 * 192 * DVS_LDB);   // parts hi, mid of the x6 triple = the x3 pair
-    dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));
-    dvs_stage_vector_perm(l.inb, a.in_b, 192);
-    dvs_stage_vector(l.outb, a.out_b, 64);
-    if (a.ln.stats) {
-        dvs_stage_vector(l.lg, a.ln.g, 64);
-        dvs_stage_vector(l.lb, a.ln.b, 64);
+    DVS_STAMP(dvs_stamps_bwd, mine, 0);
+    if (stage_mine) {
+        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        __syncthreads();
     }
-    if (dvs_tid() < 2) l.gcount[dvs_tid()] = 0;
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_bwd, mine, 1);
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N, B = a.dims.B;
@@ -644,21 +748,32 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         dvs_coop_dw_bf(aWo, abo, (const dvs_bf16*)l.slots, (const dvs_bf16*)l.slots + 2 * DVS_SCR, 2 * 2 * DVS_SCR, L);
         dvs_group_barrier(G, L);
     }
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    DvsBwdTail tail;
+    dvs_tail_issue(tail, next, has_next);
+    DVS_STAMP(dvs_stamps_bwd, mine, 3);
+    dvs_lds_barrier();
+    DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
-    dvs_coop_store((float*)smem, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
-    float* red = (float*)smem;
+    float* const bufo = (float*)smem;
+    float* red = bufo + 4096;
+    dvs_coop_stage(bufo, aWo, L);
     red[L.wave * 64 + L.lane] = 0.f;
     dvs_wave_sync();
     if (L.r == 0) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) red[L.wave * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = abo[reg];
     }
-    __syncthreads();
+    dvs_lds_barrier();
+    dvs_coop_flush(bufo, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
     if (dvs_tid() < 64) {
         float s = 0.f;
         for (int w = 0; w < 8; ++w) s += red[w * 64 + dvs_tid()];
         slab[a.o_out_b + dvs_tid()] = s;
     }
+    DVS_STAMP(dvs_stamps_bwd, mine, 5);
+    dvs_lds_barrier();
+    dvs_tail_commit(tail, next, has_next, smem);
+    DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }
 

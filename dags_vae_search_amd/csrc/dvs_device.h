@@ -99,6 +99,20 @@ __device__ __forceinline__ void dvs_wave_sync() {
 #endif
 }
 
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also drains the wave's vector-memory queue
+// (s_waitcnt vmcnt(0)): behind it a phase tail's prefetch loads (dvs_stage.h) would be waited for by every wave BEFORE the
+// barrier, which puts the last wave's load latency back on the critical path.  Global tiles need no workgroup ordering
+// here: every tile / statistics line is written and later read by the SAME wave (one in-order memory queue per wave).
+__device__ __forceinline__ void dvs_lds_barrier() {
+#ifdef DVS_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+}
+
 #ifdef DVS_EMU
 #define DVS_SCHED_FENCE() ((void)0)
 #else

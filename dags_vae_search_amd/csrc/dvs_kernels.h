@@ -2,6 +2,7 @@
 #pragma once
 #include "dvs_device.h"
 #include "dvs_host.h"
+#include "dvs_stage.h"
 
 #ifndef DVS_EMU
 typedef hipStream_t dvs_stream_t;
@@ -123,7 +124,9 @@ struct FwdPhase {
 struct FwdStackArgs {
     int nphase, pad;
     FwdPhase ph[DVS_FWD_STACK_PHASES];
+    DvsStagePlan plan[DVS_FWD_STACK_PHASES];     // filled by dvs_launch_fwd_stack (dvs_stage.h)
 };
+static_assert(sizeof(FwdStackArgs) <= 4096, "kernel argument block limit");
 void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 encoder, 1 decoder (profile names)
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st);
 int dvs_attn_fwd_waves();

@@ -1,0 +1,192 @@
+// Staging plans: what a phase of a chained launch (k_fwd_stack / k_bwd_stack) keeps in LDS besides its per-wave
+// scratch — weight images (16-byte segments copied verbatim from the per-step images, dvs_wimg.h) and small vectors
+// (biases, LayerNorm parameters; optionally permuted by dvs_pi) — described as data, so that the PREVIOUS phase can fetch
+// it while its own tail runs:
+//
+//     phase p:   [DAG loop] -> issue(plan of p+1): global loads into registers, nothing waits for them
+//                -> workgroup barrier -> epilogue of p (gradient slabs; uses LDS) -> workgroup barrier
+//                -> commit(plan of p+1): registers -> LDS                                  -> workgroup barrier
+//     phase p+1: [DAG loop] ...
+//
+// Round 1 staged every phase's images behind the closing barrier of the phase before: 5-9 k cycles per phase (8-15 % of a
+// backward phase) in which no wave of the workgroup computes.  With the loads issued ahead of that barrier
+// their latency hides behind the barrier wait (the older wave group idles 8-20 k cycles there) and the epilogue.  The
+// registers are free at that point — the DAG loop's state is dead — and live only inside the phase function's tail, so
+// nothing is carried round the phase loop (round 1's attempt carried them and the compiler spilled every one).
+#pragma once
+#include "dvs_device.h"
+
+constexpr int DVS_PLAN_SEGS = 2;       // dvs_plan_chunk is written for exactly two
+constexpr int DVS_PLAN_VECS = 6;
+struct DvsStagePlan {
+    const f4* src[DVS_PLAN_SEGS];      // global source of segment s (16-byte aligned)
+    int dst16[DVS_PLAN_SEGS];          // LDS destination, in 16-byte units from the start of dynamic LDS
+    int n16[DVS_PLAN_SEGS];            // length in 16-byte units
+    const float* vsrc[DVS_PLAN_VECS];  // small vectors: element i of vector j goes to LDS float vdst[j] + i
+    int vdst[DVS_PLAN_VECS];
+    int vlen[DVS_PLAN_VECS];           // <= 256 floats
+    int vperm;                         // bit j: vector j is read through dvs_pi (attention slot order)
+    int nseg, nvec;
+    int zero_int;                      // LDS int index of two group-barrier counters to clear, or -1
+    int phase;                         // index of the phase inside its chained launch (diagnostic stamps, tools/phase_stamps.py)
+};
+
+// Diagnostic build only (make STAMPS=1 -> libdvs_hip_stamps.so, never shipped or loaded by the package): lane 0 of every
+// wave records s_memtime at fixed points of every phase; tools/phase_stamps.py turns them into a per-phase time budget.
+#ifdef DVS_STAMPS
+constexpr int DVS_STAMP_IDS = 8, DVS_STAMP_PHASES = 32, DVS_STAMP_WAVES = 8, DVS_STAMP_WGS = 256;
+#define DVS_STAMP_DECL(name) __device__ unsigned long long name[DVS_STAMP_WGS * DVS_STAMP_WAVES * DVS_STAMP_PHASES * DVS_STAMP_IDS]
+#define DVS_STAMP(buf, pp, id)                                                                                              \
+    do {                                                                                                                    \
+        if ((dvs_tid() & 63) == 0 && dvs_bid() < DVS_STAMP_WGS && (dvs_tid() >> 6) < DVS_STAMP_WAVES)                        \
+            buf[(((size_t)dvs_bid() * DVS_STAMP_WAVES + (dvs_tid() >> 6)) * DVS_STAMP_PHASES + ((pp)->phase & 31)) *          \
+                    DVS_STAMP_IDS + (id)] = __builtin_amdgcn_s_memtime();                                                    \
+    } while (0)
+#else
+#define DVS_STAMP(buf, pp, id) ((void)0)
+#endif
+
+// Plans are built on the HOST by the launchers (the LDS layout functions are __host__ __device__) and travel in the kernel
+// argument block: device code reads their fields where it needs them (scalar loads) instead of deriving ~40 uniform values
+// per phase in registers — computed on the device they cost the chained kernels 171 SGPR spills.
+#ifndef DVS_EMU
+#define DVS_HD __host__ __device__
+#else
+#define DVS_HD
+#endif
+#define DVS_FAKE_LDS ((char*)(uintptr_t)(1u << 20))      // host-side stand-in for the dynamic-LDS base: only differences are used
+DVS_HD inline void dvs_plan_clear(DvsStagePlan& p) {
+    for (int i = 0; i < DVS_PLAN_SEGS; ++i) {
+        p.src[i] = nullptr;
+        p.dst16[i] = 0;
+        p.n16[i] = 0;
+    }
+    for (int i = 0; i < DVS_PLAN_VECS; ++i) {
+        p.vsrc[i] = nullptr;
+        p.vdst[i] = 0;
+        p.vlen[i] = 0;
+    }
+    p.phase = 0;
+    p.nseg = 0;
+    p.nvec = 0;
+    p.vperm = 0;
+    p.zero_int = -1;
+}
+DVS_HD inline void dvs_plan_seg(DvsStagePlan& p, const char* smem, const void* lds_dst, const void* src, int n_bf16) {
+    p.src[p.nseg] = (const f4*)src;
+    p.dst16[p.nseg] = (int)(((const char*)lds_dst - smem) >> 4);
+    p.n16[p.nseg] = n_bf16 >> 3;
+    ++p.nseg;
+}
+DVS_HD inline void dvs_plan_vec(DvsStagePlan& p, const char* smem, const float* lds_dst, const float* src, int n,
+                                bool perm = false) {
+    p.vsrc[p.nvec] = src;
+    p.vdst[p.nvec] = (int)(((const char*)lds_dst - smem) >> 2);
+    p.vlen[p.nvec] = n;
+    if (perm) p.vperm |= 1 << p.nvec;
+    ++p.nvec;
+}
+
+// Registers of one thread's share of a plan: NCH x 16 bytes of image data and one float per small vector.  In the chained
+// kernels only the OLDER wave group (waves 0-3, DVS_PF_THREADS threads) fetches: it leaves its DAG loop 5-17 k cycles ahead
+// of the younger group (age-priority arbitration between the two waves of a SIMD; tools/phase_stamps.py) and idles at the
+// closing barrier anyway, while the younger group's tail is the workgroup's critical path — issuing its share there cost
+// that path 2.3-3.5 k cycles per phase.  256 threads: the backward's largest plan (attention: 73 KB) needs 18 chunks, the
+// forward's (attention x6 images: 108 KB) 27.  Per-phase launches stage with the whole workgroup (9 / 14 chunks at 512).
+constexpr int DVS_PF_THREADS = 256;
+constexpr int DVS_PF_BWD = 9, DVS_PF_FWD = 14, DVS_PF_BWD_TAIL = 18, DVS_PF_FWD_TAIL = 27;
+template <int NCH>
+struct DvsPrefetch {
+    f4 v[NCH];
+    float s[DVS_PLAN_VECS];
+};
+
+// The device functions below take the plan through a pointer type PP: a plain pointer (per-phase kernels: the plan is a
+// kernel argument of its own) or a pointer into the CONSTANT address space (chained kernels: k_bwd_stack / k_fwd_stack read
+// their plan table straight from the kernel-argument segment, __builtin_amdgcn_kernarg_segment_ptr).  Indexing the table
+// through a reference to the by-value argument struct made hipcc copy the whole 3.7 KB argument block to scratch memory and
+// route EVERY argument access through it (554 scratch loads in k_bwd_stack).
+#ifndef DVS_EMU
+typedef const __attribute__((address_space(4))) DvsStagePlan* DvsPlanK;       // plan inside the kernel-argument segment
+#else
+typedef const DvsStagePlan* DvsPlanK;
+#endif
+
+// Every load below is UNCONDITIONAL (indices are clamped, unused entries point at valid memory: dvs_plan_seal): a load
+// under a runtime condition makes hipcc branch around it and wait for it (vmcnt(0)) before the next one — 9-14 dependent
+// L2 round trips per phase instead of one batch in flight (measured: the first version of this file, with `if (k < total)
+// v = *src`, made the chained kernels 10-20 % SLOWER than staging behind the barrier).  Only the LDS stores are predicated.
+DVS_HD inline void dvs_plan_seal(DvsStagePlan& p) {
+    for (int i = 0; i < DVS_PLAN_SEGS; ++i)
+        if (i >= p.nseg || !p.src[i]) {
+            p.src[i] = p.src[0];
+            p.n16[i] = 0;
+        }
+    for (int i = 0; i < DVS_PLAN_VECS; ++i)
+        if (i >= p.nvec || !p.vsrc[i] || p.vlen[i] <= 0) {
+            p.vsrc[i] = (const float*)p.src[0];
+            p.vlen[i] = 0;
+        }
+}
+
+// Every workgroup of the launch fetches the SAME images at about the same time: each starts at a different chunk so that
+// they do not all queue on the same L2 lines (dvs_copy_image's rotation).
+__device__ __forceinline__ int dvs_plan_rot(int total) {
+    return (int)(((unsigned)dvs_bid() * 2654435761u) % (unsigned)(total > 0 ? total : 1));
+}
+// chunk k of thread-slot order -> rotated chunk index, source address and LDS float4 index (two segments)
+template <class PP>
+__device__ __forceinline__ void dvs_plan_chunk(PP p, int k, int total, int rot, const f4*& src, int& dst) {
+    const int n0 = p->n16[0];
+    int kr = (k < total ? k : 0) + rot;
+    kr = kr >= total ? kr - total : kr;
+    const bool s1 = kr >= n0;
+    const int off = s1 ? kr - n0 : kr;
+    src = (s1 ? p->src[1] : p->src[0]) + off;
+    dst = (s1 ? p->dst16[1] : p->dst16[0]) + off;
+}
+
+// tid / step: index of this thread among the `step` threads that share the plan (the whole workgroup, or its first
+// DVS_PF_THREADS threads in a chained kernel's tail; callers keep the other threads out)
+template <int NCH, class PP>
+__device__ __forceinline__ void dvs_prefetch_issue(DvsPrefetch<NCH>& pf, PP p, int tid, int step) {
+    const int total = p->n16[0] + p->n16[1], rot = dvs_plan_rot(total);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const f4* src;
+        int dst;
+        dvs_plan_chunk(p, tid + u * step, total, rot, src, dst);
+        pf.v[u] = *src;
+    }
+#pragma unroll
+    for (int j = 0; j < DVS_PLAN_VECS; ++j) {
+        const int len = p->vlen[j];
+        const int idx = tid < len ? tid : 0;
+        pf.s[j] = p->vsrc[j][((p->vperm >> j) & 1) ? dvs_pi(idx) : idx];
+    }
+}
+template <int NCH, class PP>
+__device__ __forceinline__ void dvs_prefetch_commit(const DvsPrefetch<NCH>& pf, PP p, char* smem, int tid, int step) {
+    const int total = p->n16[0] + p->n16[1], rot = dvs_plan_rot(total);
+    f4* lds = (f4*)smem;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const f4* src;
+        int dst;
+        dvs_plan_chunk(p, tid + u * step, total, rot, src, dst);
+        if (tid + u * step < total) lds[dst] = pf.v[u];
+    }
+    float* ldsf = (float*)smem;
+#pragma unroll
+    for (int j = 0; j < DVS_PLAN_VECS; ++j)
+        if (tid < p->vlen[j]) ldsf[p->vdst[j] + tid] = pf.s[j];
+    if (p->zero_int >= 0 && tid < 2) ((int*)smem)[p->zero_int + tid] = 0;
+}
+// Stage a plan right away (first phase of a launch, per-phase launches): all loads in flight, then the stores.  The plan
+// must fit NCH chunks per thread at this workgroup size (a 1024-thread workgroup needs half as many).
+template <int NCH, class PP>
+__device__ __forceinline__ void dvs_stage_now(PP p, char* smem) {
+    DvsPrefetch<NCH> pf;
+    dvs_prefetch_issue(pf, p, dvs_tid(), (int)blockDim.x);
+    dvs_prefetch_commit(pf, p, smem, dvs_tid(), (int)blockDim.x);
+}

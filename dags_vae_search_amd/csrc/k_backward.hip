@@ -1,45 +1,51 @@
 // Backward kernels of the transformer stack (phases: dvs_bwd_phases.h) and the slab reduce.
 #include "dvs_bwd_phases.h"
 
-__global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a) {
+__global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_ffn_bwd_phase(a, smem);
+    dvs_ffn_bwd_phase(a, smem, &plan, true, &plan, false);
 }
 void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffnb_lds_bytes();
+    DvsStagePlan plan;
+    ffnb_plan(plan, a, DVS_FAKE_LDS);
     DVS_SET_LDS(k_ffn_bwd, lds);
-    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(512), lds, st, a);
+    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(512), lds, st, a, plan);
 }
 
 template <int NPROJ>
-__global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a) {
+__global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_proj_bwd_phase<NPROJ>(a, smem);
+    dvs_proj_bwd_phase<NPROJ>(a, smem, &plan, true, &plan, false);
 }
 
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
     const size_t bytes = projb_lds_bytes(nproj);
+    DvsStagePlan plan;
+    projb_plan(plan, a, nproj, DVS_FAKE_LDS);
     if (nproj == 3) {
         DVS_SET_LDS(k_proj_bwd<3>, bytes);
-        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(512), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(512), bytes, st, a, plan);
     } else if (nproj == 2) {
         DVS_SET_LDS(k_proj_bwd<2>, bytes);
-        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(512), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(512), bytes, st, a, plan);
     } else {
         DVS_SET_LDS(k_proj_bwd<1>, bytes);
-        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(512), bytes, st, a);
+        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(512), bytes, st, a, plan);
     }
 }
 
-__global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a) {
+__global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_attn_bwd_phase(a, smem);
+    dvs_attn_bwd_phase(a, smem, &plan, true, &plan, false);
 }
 
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attnb_lds_floats() * 4;
+    DvsStagePlan plan;
+    attnb_plan(plan, a, DVS_FAKE_LDS);
     DVS_SET_LDS(k_attn_bwd, lds);
-    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(512), lds, st, a);
+    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(512), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -50,20 +56,42 @@ void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
 template <int TAG>
 __global__ __launch_bounds__(512) void k_bwd_stack(BwdStackArgs s) {
     DVS_DYN_LDS(smem);
+    // the plan table is read straight from the kernel-argument segment (dvs_stage.h); the struct is the kernel's only
+    // explicit argument, so it starts at offset 0 of the segment
+#ifndef DVS_EMU
+    const DvsPlanK plans =
+        ((const __attribute__((address_space(4))) BwdStackArgs*)__builtin_amdgcn_kernarg_segment_ptr())->plan;
+#else
+    const DvsPlanK plans = s.plan;
+#endif
     for (int i = 0; i < s.nphase; ++i) {
         const BwdPhase& ph = s.ph[i];
+        const bool first = i == 0;                       // later phases: staged by the tail of the one before (dvs_stage.h)
+        const bool more = i + 1 < s.nphase;
+        const DvsPlanK mine = plans + i;
+        const DvsPlanK next = plans + (more ? i + 1 : i);
         switch (ph.kind) {
-            case DVS_PH_FFN: dvs_ffn_bwd_phase(ph.u.f, smem); break;
-            case DVS_PH_ATTN: dvs_attn_bwd_phase(ph.u.a, smem); break;
-            case DVS_PH_PROJ1: dvs_proj_bwd_phase<1>(ph.u.p, smem); break;
-            case DVS_PH_PROJ2: dvs_proj_bwd_phase<2>(ph.u.p, smem); break;
-            default: dvs_proj_bwd_phase<3>(ph.u.p, smem); break;
+            case DVS_PH_FFN: dvs_ffn_bwd_phase(ph.u.f, smem, mine, first, next, more); break;
+            case DVS_PH_ATTN: dvs_attn_bwd_phase(ph.u.a, smem, mine, first, next, more); break;
+            case DVS_PH_PROJ1: dvs_proj_bwd_phase<1>(ph.u.p, smem, mine, first, next, more); break;
+            case DVS_PH_PROJ2: dvs_proj_bwd_phase<2>(ph.u.p, smem, mine, first, next, more); break;
+            default: dvs_proj_bwd_phase<3>(ph.u.p, smem, mine, first, next, more); break;
         }
-        __syncthreads();     // the epilogue's LDS scratch is the next phase's weight image; global tiles: same wave, same CU
+        dvs_lds_barrier();   // publishes the next phase's staged images (tail commit); global tiles: same wave, same queue
     }
 }
 
-void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t st) {
+void dvs_launch_bwd_stack(const BwdStackArgs& s_in, int tag, int grid, dvs_stream_t st) {
+    BwdStackArgs s = s_in;
+    for (int i = 0; i < s.nphase; ++i) {
+        dvs_bwd_plan(s.plan[i], s.ph[i], DVS_FAKE_LDS);
+        s.plan[i].phase = i;
+    }
+#ifdef DVS_STAMPS
+    static int stamp_seq = 0;            // three chained launches per step: decoder 1, decoder 2, encoder
+    for (int i = 0; i < s.nphase; ++i) s.plan[i].phase = (stamp_seq % 3) * DVS_STACK_PHASES + i;
+    ++stamp_seq;
+#endif
     size_t lds = 0;
     for (int i = 0; i < s.nphase; ++i) {
         const int k = s.ph[i].kind;
@@ -116,3 +144,15 @@ void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st) {
     const int64_t n4 = (a.P + 3) / 4;
     DVS_LAUNCH(k_reduce_slabs, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, a);
 }
+
+#ifdef DVS_STAMPS
+extern "C" int dvs_debug_read_stamps_bwd(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_bwd)) bytes = sizeof(dvs_stamps_bwd);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_bwd), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_bwd)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_bwd)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif

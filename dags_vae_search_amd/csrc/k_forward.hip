@@ -287,11 +287,14 @@ void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
 // tile store stays in registers:  q^T,k^T (T) -> S^T = K Q^T per head (lane r = query i, regs = keys 4g..4g+3)
 // -> softmax over keys (in-lane + 2 shuffles) -> O^T = V^T P^T -> y^T = Wo O^T.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef DVS_STAMPS
+DVS_STAMP_DECL(dvs_stamps_fwd);
+#endif
 struct AttnLds {
     dvs_bf16 *Win, *Wout;                     // bf16x6 image triples (dvs_bf16.h); in-projection rows / out-projection columns in slot order
     float *inb, *outb, *lg, *lb;
 };
-__device__ __forceinline__ AttnLds attn_lds(char* smem) {
+DVS_HD inline AttnLds attn_lds(char* smem) {
     AttnLds l;
     l.Win = (dvs_bf16*)smem;
     l.Wout = l.Win + 3 * 192 * DVS_LDB;
@@ -303,16 +306,17 @@ __device__ __forceinline__ AttnLds attn_lds(char* smem) {
 }
 static size_t attn_lds_bytes() { return 3 * 256 * DVS_LDB * sizeof(dvs_bf16) + (192 + 64 + 128) * sizeof(float); }
 
-__device__ __forceinline__ void attn_stage(const AttnLds& l, const void* wimg, const float* in_b, const float* out_b,
-                                           const DvsLN& ln) {
+// staging plan (dvs_stage.h), built on the host by the launchers
+inline void attn_plan(DvsStagePlan& p, const AttnArgs& a, char* smem) {
+    const AttnLds l = attn_lds(smem);
+    dvs_plan_clear(p);
     // Win (rows in head-aligned slot order) and Wout (columns likewise) as ready-made bf16x6 images: one straight copy
-    dvs_copy_image(l.Win, (const dvs_bf16*)wimg + DvsAttnImg::Win, (int)(DvsAttnImg::WoutT - DvsAttnImg::Win));
-    dvs_stage_vector_perm(l.inb, in_b, 192);
-    dvs_stage_vector(l.outb, out_b, 64);
-    if (ln.stats) {
-        dvs_stage_vector(l.lg, ln.g, 64);
-        dvs_stage_vector(l.lb, ln.b, 64);
-    }
+    dvs_plan_seg(p, smem, l.Win, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, (int)(DvsAttnImg::WoutT - DvsAttnImg::Win));
+    dvs_plan_vec(p, smem, l.inb, a.in_b, 192, true);
+    dvs_plan_vec(p, smem, l.outb, a.out_b, 64);
+    dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
+    dvs_plan_seal(p);
 }
 
 // q^T, k^T (T-layout, q pre-scaled by 1/sqrt(dh)) and v (N-layout) of one DAG; fp32-accurate bf16x6 products
@@ -396,10 +400,18 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
 #ifndef DVS_ATTN_FWD_THREADS
 #define DVS_ATTN_FWD_THREADS 512
 #endif
-__device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem) {
+// mine / stage_mine, next / has_next: staging plans of this phase and of the one that follows in a chained launch
+// (dvs_stage.h): the next phase's images are fetched into registers behind this phase's DAG loop, ahead of the barrier.
+template <class PP>
+__device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem, PP mine, bool stage_mine, PP next,
+                                                   bool has_next) {
     const AttnLds l = attn_lds(smem);
-    attn_stage(l, a.wimg, a.in_b, a.out_b, a.ln);
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_fwd, mine, 0);
+    if (stage_mine) {
+        dvs_stage_now<DVS_PF_FWD>(mine, smem);
+        __syncthreads();
+    }
+    DVS_STAMP(dvs_stamps_fwd, mine, 1);
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
@@ -455,18 +467,32 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
             for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
         dvs_store_pre(a.out_pre, a.out_stats, dag, y, L);
     }
+    DVS_STAMP(dvs_stamps_fwd, mine, 2);
+    if (has_next) {
+        // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
+        DvsPrefetch<DVS_PF_FWD_TAIL> pf;
+        const bool fetcher = dvs_tid() < DVS_PF_THREADS;
+        if (fetcher) dvs_prefetch_issue(pf, next, dvs_tid(), DVS_PF_THREADS);
+        DVS_STAMP(dvs_stamps_fwd, mine, 3);
+        dvs_lds_barrier();               // every wave is done with this phase's images
+        DVS_STAMP(dvs_stamps_fwd, mine, 4);
+        if (fetcher) dvs_prefetch_commit(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+        DVS_STAMP(dvs_stamps_fwd, mine, 6);
+    }
 }
 
-__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_attn_fwd_phase(a, smem);
+    dvs_attn_fwd_phase(a, smem, &plan, true, &plan, false);
 }
 
 int dvs_attn_fwd_waves() { return DVS_ATTN_FWD_THREADS / 64; }
 void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = attn_lds_bytes();
+    DvsStagePlan plan;
+    attn_plan(plan, a, DVS_FAKE_LDS);
     DVS_SET_LDS(k_attn_fwd, lds);
-    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a);
+    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -476,7 +502,7 @@ struct FfnLds {
     dvs_bf16 *W1, *W2;                        // bf16x6 image triples (dvs_bf16.h): fp32-accurate products on the bf16 pipe
     float *b1, *b2, *lg, *lb, *ng, *nb;
 };
-__device__ __forceinline__ FfnLds ffn_lds(char* smem) {
+DVS_HD inline FfnLds ffn_lds(char* smem) {
     FfnLds l;
     l.W1 = (dvs_bf16*)smem;
     l.W2 = l.W1 + 3 * 64 * DVS_LDB;
@@ -490,20 +516,29 @@ __device__ __forceinline__ FfnLds ffn_lds(char* smem) {
 }
 static size_t ffn_lds_bytes() { return 6 * 64 * DVS_LDB * sizeof(dvs_bf16) + 6 * 64 * sizeof(float); }
 
-__device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem) {
+inline void ffn_plan(DvsStagePlan& p, const FfnArgs& a, char* smem) {
     const FfnLds l = ffn_lds(smem);
-    dvs_copy_image(l.W1, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(6 * DVS_IMG64));     // W1, W2 bf16x6 images
-    dvs_stage_vector(l.b1, a.l1_b, 64);
-    dvs_stage_vector(l.b2, a.l2_b, 64);
-    if (a.ln.stats) {
-        dvs_stage_vector(l.lg, a.ln.g, 64);
-        dvs_stage_vector(l.lb, a.ln.b, 64);
+    dvs_plan_clear(p);
+    dvs_plan_seg(p, smem, l.W1, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(6 * DVS_IMG64));     // W1, W2 bf16x6 images
+    dvs_plan_vec(p, smem, l.b1, a.l1_b, 64);
+    dvs_plan_vec(p, smem, l.b2, a.l2_b, 64);
+    dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
+    dvs_plan_vec(p, smem, l.ng, a.ng, a.out_norm ? 64 : 0);
+    dvs_plan_vec(p, smem, l.nb, a.nb, a.out_norm ? 64 : 0);
+    dvs_plan_seal(p);
+}
+
+template <class PP>
+__device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, PP mine, bool stage_mine, PP next,
+                                                  bool has_next) {
+    const FfnLds l = ffn_lds(smem);
+    DVS_STAMP(dvs_stamps_fwd, mine, 0);
+    if (stage_mine) {
+        dvs_stage_now<DVS_PF_FWD>(mine, smem);
+        __syncthreads();
     }
-    if (a.out_norm) {
-        dvs_stage_vector(l.ng, a.ng, 64);
-        dvs_stage_vector(l.nb, a.nb, 64);
-    }
-    __syncthreads();
+    DVS_STAMP(dvs_stamps_fwd, mine, 1);
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int ntiles = a.dims.B * a.dims.NT;
@@ -550,18 +585,32 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem) 
             dvs_store_tile(a.out_norm, tile, xn, L);
         }
     }
+    DVS_STAMP(dvs_stamps_fwd, mine, 2);
+    if (has_next) {
+        // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
+        DvsPrefetch<DVS_PF_FWD_TAIL> pf;
+        const bool fetcher = dvs_tid() < DVS_PF_THREADS;
+        if (fetcher) dvs_prefetch_issue(pf, next, dvs_tid(), DVS_PF_THREADS);
+        DVS_STAMP(dvs_stamps_fwd, mine, 3);
+        dvs_lds_barrier();               // every wave is done with this phase's images
+        DVS_STAMP(dvs_stamps_fwd, mine, 4);
+        if (fetcher) dvs_prefetch_commit(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+        DVS_STAMP(dvs_stamps_fwd, mine, 6);
+    }
 }
 
 // 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.
-__global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a) {
+__global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_ffn_fwd_phase(a, smem);
+    dvs_ffn_fwd_phase(a, smem, &plan, true, &plan, false);
 }
 
 void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = ffn_lds_bytes();
+    DvsStagePlan plan;
+    ffn_plan(plan, a, DVS_FAKE_LDS);
     DVS_SET_LDS(k_ffn_fwd, lds);
-    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a);
+    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -572,15 +621,34 @@ void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
 template <int TAG>
 __global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
     DVS_DYN_LDS(smem);
+    // the plan table is read straight from the kernel-argument segment (dvs_stage.h): the struct is the only explicit argument
+#ifndef DVS_EMU
+    const DvsPlanK plans =
+        ((const __attribute__((address_space(4))) FwdStackArgs*)__builtin_amdgcn_kernarg_segment_ptr())->plan;
+#else
+    const DvsPlanK plans = s.plan;
+#endif
     for (int i = 0; i < s.nphase; ++i) {
         const FwdPhase& ph = s.ph[i];
-        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem);
-        else dvs_ffn_fwd_phase(ph.u.f, smem);
-        __syncthreads();
+        const bool first = i == 0, more = i + 1 < s.nphase;
+        const DvsPlanK mine = plans + i;
+        const DvsPlanK next = plans + (more ? i + 1 : i);
+        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem, mine, first, next, more);
+        else dvs_ffn_fwd_phase(ph.u.f, smem, mine, first, next, more);
+        dvs_lds_barrier();               // publishes the next phase's staged images
     }
 }
 
-void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, dvs_stream_t st) {
+void dvs_launch_fwd_stack(const FwdStackArgs& s_in, int tag, int grid, dvs_stream_t st) {
+    FwdStackArgs s = s_in;
+    for (int i = 0; i < s.nphase; ++i) {
+        if (s.ph[i].kind == DVS_FPH_ATTN) attn_plan(s.plan[i], s.ph[i].u.a, DVS_FAKE_LDS);
+        else ffn_plan(s.plan[i], s.ph[i].u.f, DVS_FAKE_LDS);
+        s.plan[i].phase = i;
+    }
+#ifdef DVS_STAMPS
+    for (int i = 0; i < s.nphase; ++i) s.plan[i].phase = tag * DVS_FWD_STACK_PHASES + i;      // encoder 0..5, decoder 9..17
+#endif
     const size_t la = attn_lds_bytes(), lf = ffn_lds_bytes();
     const size_t lds = la > lf ? la : lf;
     if (tag == 0) {
@@ -606,3 +674,15 @@ void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st) {
     const size_t n = (size_t)B * 1024;
     DVS_LAUNCH(k_unfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, frag, out, B);
 }
+
+#ifdef DVS_STAMPS
+extern "C" int dvs_debug_read_stamps_fwd(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_fwd)) bytes = sizeof(dvs_stamps_fwd);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_fwd), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_fwd)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_fwd)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif

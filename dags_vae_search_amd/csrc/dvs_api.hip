@@ -444,11 +444,11 @@ static void prepare_images(const DvsLayout& L, bool wide, const float* params, f
     };
     auto attn = [&](const DvsAttnP& p, int block) {
         const size_t b = img_attn(block);
-        if (!wide) {             // the wide attention kernels keep fp32 images of their own
-            add(p.in_w, b + DvsAttnImg::Win, 192, 2);                 // x6, rows in slot order
-            add(p.out_w, b + DvsAttnImg::Wout, 64, 4);                // x6, columns in slot order
-            add(p.out_w, b + DvsAttnImg::WoutT, 64, 1 | 4);           // x3 transposed, image rows in slot order
-        }
+        // the one-tile kernels keep q, k, v in head-aligned slot order (dvs_pi: in-projection rows / out-projection columns
+        // permuted); the wide kernels (k_wide_fwd.hip) use parameter order
+        add(p.in_w, b + DvsAttnImg::Win, 192, wide ? 0 : 2);             // x6
+        add(p.out_w, b + DvsAttnImg::Wout, 64, wide ? 0 : 4);            // x6
+        add(p.out_w, b + DvsAttnImg::WoutT, 64, 1 | (wide ? 0 : 4));     // x3 transposed
         for (int q = 0; q < 3; ++q)                                    // W_q^T, W_k^T, W_v^T for k_proj_bwd
             add(p.in_w + 4096 * q, b + DvsAttnImg::WinT + (size_t)q * 2 * DVS_IMG64, 64, 1 | (wide ? 0 : 2));
     };

@@ -1,6 +1,7 @@
 // Wide path (17..48 tokens per DAG), forward kernels: records, embedding, attention sublayer, loss head.
 // See dvs_wide.h for the execution model (workgroup = DAG, wave = 16-token tile, tiles meet in LDS).
 #include "dvs_wide.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // dvs_pack_features, wide records: one thread per (DAG, token slot).  Same checks as k_pack (k_forward.hip).
@@ -207,163 +208,274 @@ void dvs_launch_embed_fwd_w(const EmbedArgs& a, int grid, dvs_stream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Attention sublayer forward, wide (same math as k_attn_fwd: pace.py:52-56 / 144 / 148).
-//   wave w < NT : x tile -> q, k, v (MFMA) -> parked in LDS      | barrier
-//   all threads : one (token i, head h) item each: scores over the ancestor bit-row of i, softmax, dropout, O = P'V
-//                 written to LDS                                  | barrier
-//   wave w < NT : y = Wo O + bo, dropout, residual, LayerNorm statistics, store
+// Attention sublayer forward, wide (same math as k_attn_fwd: pace.py:52-56 / 144 / 148), one workgroup (8 waves) per DAG.
+//   stage 1  waves 0 .. 2 NT - 1: wave (tile w, half) computes half of the packed in-projection rows of tile w — q and
+//            k[0:32] (half 0) or k[32:64] and v (half 1) — with the narrow path's fp32-accurate bf16x6 products from the
+//            per-step weight images (dvs_wimg.h), and parks them row-major in LDS (Q pre-scaled by 1/sqrt(dh))  | barrier
+//   stage 2  wave h = head h: for every query tile it the scores S^T[key][query] of the NT key tiles (2 MFMAs each, K = the
+//            8 features of the head), the ancestor mask from the query's bit-row, softmax over up to 48 keys (in-lane + two
+//            shuffles), dropout, O^T = V^T P^T (4 MFMAs per key tile on the 16 features of the head PAIR; the 8 rows of
+//            the other head are discarded) written over the head's own slice of Q                                | barrier
+//   stage 3  wave w < NT: y = Wo O + bo (bf16x6), dropout, residual, LayerNorm statistics, store                 | barrier
+// Round 1 ran the core as a VALU walk of every (token, head) bit-row (15 k of the kernel's 24 k cycles per DAG) and the
+// projections as exact-fp32 MFMAs on 3 of the 8 waves (8 k cycles).
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWLds {
-    float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *O;
-    uint64_t* rows;              // [3][48]: ancestor bit-rows of the current DAG, their even / odd set bits
+    dvs_bf16 *Win, *Wout;        // bf16x6 image triples, rows / columns in PARAMETER order (no head-slot permutation here)
+    float *inb, *outb, *lg, *lb, *Q, *K, *V;       // O overwrites Q (every (token, head) slice is read before it is written)
+    uint64_t* rows;              // [48]: ancestor bit-rows of the current DAG (0 for padding tokens)
 };
 __device__ __forceinline__ AttnWLds attnw_lds(char* smem) {
     AttnWLds l;
-    l.Win = (float*)smem;
-    l.Wout = l.Win + 192 * DVS_LD;
-    l.inb = l.Wout + 64 * DVS_LD;
+    l.Win = (dvs_bf16*)smem;
+    l.Wout = l.Win + 3 * 192 * DVS_LDB;
+    l.inb = (float*)(l.Wout + 3 * 64 * DVS_LDB);
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
     l.Q = l.lb + 64;
     l.K = l.Q + DVS_WSCR;
     l.V = l.K + DVS_WSCR;
-    l.O = l.V + DVS_WSCR;
-    l.rows = (uint64_t*)(l.O + DVS_WSCR);        // float offset is even: 8-byte aligned
+    l.rows = (uint64_t*)(l.V + DVS_WSCR);        // byte offset is a multiple of 8
     return l;
 }
-constexpr size_t ATTNW_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR + 6 * DVS_WTOK;
+constexpr size_t ATTNW_BYTES = 3 * 256 * DVS_LDB * sizeof(dvs_bf16) + (192 + 64 + 128 + 3 * (size_t)DVS_WSCR) * 4 + DVS_WTOK * 8;
 
-// 8 waves: waves 0..NT-1 own the tiles (MFMA parts), all 8 share the (token, head) items of the core.
+// one output tile (16 features ot) of a T-layout product, parked row-major: rows tok0 + r, columns 16 ot + 4g ..
+__device__ __forceinline__ void dvs_park_col(float* buf, int tok0, int ot, const f4& v, const Lane& L) {
+    *(f4*)(buf + (tok0 + L.r) * DVS_LD + 16 * ot + 4 * L.g) = v;
+}
+
+#ifdef DVS_STAMPS
+__device__ unsigned long long dvs_stamps_w[256 * 8 * 8];
+#define WSTAMP(k)                                                                                           \
+    do {                                                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) dvs_stamps_w[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] += now_ - wst_; \
+        wst_ = now_;                                                                                        \
+    } while (0)
+extern "C" int dvs_debug_read_stamps_w(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_w)) bytes = sizeof(dvs_stamps_w);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_w), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_w)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_w)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#else
+#define WSTAMP(k) ((void)0)
+#endif
+
 __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
     DVS_DYN_LDS(smem);
     const AttnWLds l = attnw_lds(smem);
-    dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
-    dvs_stage_matrix(l.Wout, DVS_LD, a.out_w, 64, 64, 64);
+#ifdef DVS_STAMPS
+    unsigned long long wst_ = __builtin_amdgcn_s_memtime();
+#endif
+    dvs_copy_image(l.Win, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, (int)(DvsAttnImg::WoutT - DvsAttnImg::Win));
     dvs_stage_vector(l.inb, a.in_b, 192);
     dvs_stage_vector(l.outb, a.out_b, 64);
     if (a.ln.stats) {
         dvs_stage_vector(l.lg, a.ln.g, 64);
         dvs_stage_vector(l.lb, a.ln.b, 64);
     }
-    for (int i = threadIdx.x; i < 4 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
     __syncthreads();
+    WSTAMP(0);
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N, NT = a.dims.NT, NTOK = 16 * NT;
-    const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
-    const bool has_tile = L.wave < NT;
     const float scale = 0.35355339059327373f;   // 1/sqrt(8)
+    const int pw = L.wave >> 1, phalf = L.wave & 1;              // stage 1: (tile, half of the in-projection rows)
+    const bool proj = L.wave < 2 * NT;
+    const int h = L.wave, hp = h >> 1, c0 = 8 * h;               // stage 2: head of this wave
+    const bool mine = (L.g >> 1) == (h & 1);                     // rows 4g.. of a head-pair tile that belong to head h
+    const bool has_tile = L.wave < NT;                           // stage 3: tile of this wave
+    const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
     for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
-        const size_t tile = (size_t)dag * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
-        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {      // a wave without a tile prepares the rows
-            const int i = threadIdx.x - 256;
-            const uint64_t row = i < N ? rec->allowed[i] : 0ull;
-            uint64_t e, o;
-            dvs_split_row(row, e, o);
-            l.rows[i] = row;
-            l.rows[DVS_WTOK + i] = e;
-            l.rows[2 * DVS_WTOK + i] = o;
+        if (threadIdx.x >= 448 && threadIdx.x < 448 + DVS_WTOK) {     // wave 7 has no projection work: it fetches the rows
+            const int i = threadIdx.x - 448;
+            l.rows[i] = i < N ? rec->allowed[i] : 0ull;
         }
-        f4 x[4];
-        if (has_tile) {
-            f4 kv[4], dummy[4];
+        // ---- stage 1 ------------------------------------------------------------------------------------------------
+        if (proj) {
+            const size_t tile = (size_t)dag * NT + pw;
+            const int ptok0 = 16 * pw, pNl = dvs_rows_of(N, pw);
+            f4 x[4], kv[4], dummy[4];
             float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, pNl, L);
             if (a.kv) {
                 dvs_load_tile(kv, a.kv, tile, L);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) kv[t] = x[t];
             }
-            f4 q[4], k[4], v[4];
+            const Split3T kvs = dvs_split3_T(kv);
+            if (phalf == 0) {
+                f4 q[4], k01[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                q[t] = dvs_vecT(l.inb, t, L);
-                k[t] = dvs_vecT(l.inb + 64, t, L);
-                v[t] = dvs_vecT(l.inb + 128, t, L);
+                for (int t = 0; t < 4; ++t) q[t] = dvs_vecT(l.inb, t, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) k01[t] = dvs_vecT(l.inb + 64, t, L);
+                dvs_matb3<4>(q, dvs_split3_T(x), l.Win, 192, 0, L);
+                dvs_matb3<2>(k01, kvs, l.Win, 192, 64, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dvs_park_col(l.Q, ptok0, t, q[t] * scale, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, t, k01[t], L);
+            } else {
+                f4 k23[2], v[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) k23[t] = dvs_vecT(l.inb + 96, t, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = dvs_vecT(l.inb + 128, t, L);
+                dvs_matb3<2>(k23, kvs, l.Win, 192, 96, L);
+                dvs_matb3<4>(v, kvs, l.Win, 192, 128, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, 2 + t, k23[t], L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dvs_park_col(l.V, ptok0, t, v[t], L);
             }
-            dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
-            dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
-            dvs_mat_T<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] *= scale;
-            dvs_park_T(l.Q + tok0 * DVS_LD, q, L);
-            dvs_park_T(l.K + tok0 * DVS_LD, k, L);
-            dvs_park_T(l.V + tok0 * DVS_LD, v, L);
         }
+        WSTAMP(1);
         __syncthreads();
+        WSTAMP(2);
+        // the residual input of stage 3: in flight while the core runs
+        f4 x[4];
+        if (has_tile) {
+            f4 dummy[4];
+            float rstd;
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, (size_t)dag * NT + L.wave, Nl, L);
+        }
+        // ---- stage 2: head h of every query tile ---------------------------------------------------------------------
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        {
-            const DvsCoreItem it = dvs_core_item(N);
-            const bool active = it.tok >= 0;
-            const int i = active ? it.tok : 0, h = it.head;
-            const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + 8 * h), q1 = *(const f4*)(l.Q + i * DVS_LD + 8 * h + 4);
-            // ONE pass over the (half) ancestor row with an online softmax (running max m, denominator and output rescaled
-            // when m grows), two keys per iteration so that their LDS reads overlap: the row walk is latency-bound.
-            // Dropout acts on the normalised probabilities; it commutes with the final division by the denominator.
-            float m = -3.0e38f, den = 0.f;
-            f4 o0 = f4_zero(), o1 = f4_zero();
-            for (uint64_t mm = active ? l.rows[(it.half + 1) * DVS_WTOK + i] : 0ull; mm;) {
-                const int j0 = dvs_ctz64(mm);
-                mm &= mm - 1;
-                const bool two = mm != 0;
-                const int j1 = two ? dvs_ctz64(mm) : j0;
-                mm &= mm - 1;                                   // no-op on 0
-                const float s0 = dvs_dot8(q0, q1, l.K + j0 * DVS_LD + 8 * h);
-                const float s1 = two ? dvs_dot8(q0, q1, l.K + j1 * DVS_LD + 8 * h) : -3.0e38f;
-                const float mn = fmaxf(m, fmaxf(s0, s1));
-                const float sc = __expf(m - mn);
-                float e0 = __expf(s0 - mn), e1 = two ? __expf(s1 - mn) : 0.f;
-                den = den * sc + (e0 + e1);
-                if (D.on) {
-                    e0 = dvs_dropout_elem(e0, kprob, (uint32_t)((h * NTOK + i) * NTOK + j0), D);
-                    e1 = dvs_dropout_elem(e1, kprob, (uint32_t)((h * NTOK + i) * NTOK + j1), D);
+        // All NT query tiles in one unrolled pass: their chains (LDS reads -> 2 + 4 dependent MFMAs per key tile -> shuffles
+        // of the softmax) are independent, and one tile alone leaves the wave waiting on every link (measured: the serial
+        // version was no faster than round 1's VALU walk).
+        float qb0[DVS_WNT], qb1[DVS_WNT];
+        uint32_t okm[DVS_WNT][2];                                  // allowed bits of keys 4g.. + 16 jt: [0] jt = 0, 1; [1] jt = 2
+        f4 s[DVS_WNT][DVS_WNT];
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) {
+            const int i = 16 * (it < NT ? it : 0) + L.r;           // query of this lane (MFMA column)
+            const uint64_t row = it < NT ? l.rows[i] : 0ull;
+            okm[it][0] = (uint32_t)(row >> (4 * L.g));
+            okm[it][1] = (uint32_t)(row >> (32 + 4 * L.g));
+            qb0[it] = l.Q[i * DVS_LD + c0 + L.g];
+            qb1[it] = l.Q[i * DVS_LD + c0 + 4 + L.g];
+        }
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            const float* kp = l.K + (16 * (jt < NT ? jt : 0) + L.r) * DVS_LD + c0 + L.g;
+            const float ka0 = kp[0], ka1 = kp[4];
+#pragma unroll
+            for (int it = 0; it < DVS_WNT; ++it) {
+                s[it][jt] = f4_zero();
+                if (it < NT && jt < NT) {
+                    s[it][jt] = dvs_mfma(ka0, qb0[it], s[it][jt]);
+                    s[it][jt] = dvs_mfma(ka1, qb1[it], s[it][jt]);
                 }
-                const float* v0 = l.V + j0 * DVS_LD + 8 * h;
-                const float* v1 = l.V + j1 * DVS_LD + 8 * h;
-                o0 = o0 * sc + *(const f4*)v0 * e0 + *(const f4*)v1 * e1;
-                o1 = o1 * sc + *(const f4*)(v0 + 4) * e0 + *(const f4*)(v1 + 4) * e1;
-                m = mn;
-            }
-            // merge the two halves of a split row (all lanes execute the exchange; whole-row lanes ignore it)
-            const float pm = dvs_pair_xchg(m), pden = dvs_pair_xchg(den);
-            const f4 po0 = dvs_pair_xchg(o0), po1 = dvs_pair_xchg(o1);
-            if (it.half >= 0) {
-                const float M = fmaxf(m, pm);
-                const float fa = __expf(m - M), fb = __expf(pm - M);
-                den = den * fa + pden * fb;
-                o0 = o0 * fa + po0 * fb;
-                o1 = o1 * fa + po1 * fb;
-            }
-            if (active && it.half <= 0) {
-                const float rden = 1.0f / den;
-                *(f4*)(l.O + i * DVS_LD + 8 * h) = o0 * rden;
-                *(f4*)(l.O + i * DVS_LD + 8 * h + 4) = o1 * rden;
             }
         }
+        // key j = 16 jt + 4g + reg is allowed iff bit j of the query's row is set
+        float m[DVS_WNT], den[DVS_WNT];
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) {
+            m[it] = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < DVS_WNT; ++jt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const bool ok = (okm[it][jt >> 1] >> (16 * (jt & 1) + reg)) & 1u;
+                    m[it] = ok ? fmaxf(m[it], s[it][jt][reg]) : m[it];
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) m[it] = fmaxf(m[it], __shfl_xor(m[it], 16));
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) m[it] = fmaxf(m[it], __shfl_xor(m[it], 32));
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) {
+            den[it] = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < DVS_WNT; ++jt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const bool ok = (okm[it][jt >> 1] >> (16 * (jt & 1) + reg)) & 1u;
+                    s[it][jt][reg] = ok ? __expf(s[it][jt][reg] - m[it]) : 0.f;
+                    den[it] += s[it][jt][reg];
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) den[it] += __shfl_xor(den[it], 16);
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) den[it] += __shfl_xor(den[it], 32);
+        f4 o[DVS_WNT];
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) {
+            o[it] = f4_zero();
+            const float rden = den[it] > 0.f ? 1.0f / den[it] : 0.f;     // padding queries have no keys: all-zero rows
+            const int i = 16 * it + L.r;
+#pragma unroll
+            for (int jt = 0; jt < DVS_WNT; ++jt) {
+                s[it][jt] *= rden;
+                if (D.on && it < NT && jt < NT) {   // element (h, i, j): index (h NTOK + i) NTOK + j, two per draw (dvs_dropout_elem)
+                    const uint32_t p0 = (uint32_t)((h * NTOK + i) * NTOK + 16 * jt + 4 * L.g) >> 1;
+                    const uint32_t h0 = dvs_draw(kprob, p0), h1 = dvs_draw(kprob, p0 + 1);
+                    s[it][jt][0] = ((h0 & 0xFFFFu) >= D.thr16) ? s[it][jt][0] * D.scale : 0.f;
+                    s[it][jt][1] = ((h0 >> 16) >= D.thr16) ? s[it][jt][1] * D.scale : 0.f;
+                    s[it][jt][2] = ((h1 & 0xFFFFu) >= D.thr16) ? s[it][jt][2] * D.scale : 0.f;
+                    s[it][jt][3] = ((h1 >> 16) >= D.thr16) ? s[it][jt][3] * D.scale : 0.f;
+                }
+            }
+        }
+        // O^T[feature 16 hp + 4g + reg][query] += V[key 16 jt + 4g' + kk][feature 16 hp + r] P^T[key][query]: the V fragment of
+        // a (key tile, kk) step serves all query tiles
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            if (jt < NT) {
+                const float* vp = l.V + (16 * jt + 4 * L.g) * DVS_LD + 16 * hp + L.r;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float va = vp[kk * DVS_LD];
+#pragma unroll
+                    for (int it = 0; it < DVS_WNT; ++it)
+                        if (it < NT) o[it] = dvs_mfma(va, s[it][jt][kk], o[it]);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it)
+            if (it < NT && mine) *(f4*)(l.Q + (16 * it + L.r) * DVS_LD + 16 * hp + 4 * L.g) = o[it];   // O over this head's slice of Q
+        WSTAMP(3);
         __syncthreads();
+        WSTAMP(4);
+        // ---- stage 3 ------------------------------------------------------------------------------------------------
         if (has_tile) {
             f4 o[4], y[4];
-            dvs_lds_T(o, l.O, tok0, L);
+            dvs_lds_T(o, l.Q, tok0, L);
 #pragma unroll
             for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);
-            dvs_mat_T<4, 4>(y, o, l.Wout, DVS_LD, 0, L);
+            dvs_matb3<4>(y, dvs_split3_T(o), l.Wout, 64, 0, L);
             dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
             const bool valid = L.r < Nl;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
-            dvs_store_pre(a.out_pre, a.out_stats, tile, y, L);
+            dvs_store_pre(a.out_pre, a.out_stats, (size_t)dag * NT + L.wave, y, L);
         }
+        WSTAMP(5);
+        __syncthreads();            // stage 3 reads O (= Q) before the next DAG's stage 1 overwrites it
+        WSTAMP(6);
     }
 }
 
 void dvs_launch_attn_fwd_w(const AttnArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = ATTNW_FLOATS * 4;
+    const size_t lds = ATTNW_BYTES;
     DVS_SET_LDS(k_attn_fwd_w, lds);
     DVS_LAUNCH(k_attn_fwd_w, dim3(grid), dim3(512), lds, st, a);
 }

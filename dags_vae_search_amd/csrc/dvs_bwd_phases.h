@@ -184,6 +184,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     float vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;                   // lane = feature
     dvs_bf16* const bslots = (dvs_bf16*)l.slots;                        // a [hi | lo] bf16 pair fills one fp32 scratch tile
     constexpr int BSTRIDE = 2 * 2 * DVS_SCR;                            // bf16 elements between the slots of two waves
+    dvs_stagger(L.wave);
     for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
         const int dag = base + L.wave;                     // tile index
         const bool live = dag < B;
@@ -347,6 +348,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
 #pragma unroll
         for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
     }
+    dvs_stagger(L.wave);
     for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
         const int dag = base + L.wave;               // tile index
         const bool live = dag < B;
@@ -525,6 +527,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     const float scale = 0.35355339059327373f;
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     f4 abo = f4_zero();                           // d out_proj.bias, rows 16*(wave&3).. like aWo
+    dvs_stagger(L.wave);
     for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
         const int dag = base + L.wave;
         const bool live = dag < B;
@@ -612,9 +615,9 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                     m[u] = mx;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 16));
+                for (int u = 0; u < 2; ++u) m[u] = dvs_max_x16(m[u]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], 32));
+                for (int u = 0; u < 2; ++u) m[u] = dvs_max_x32(m[u]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float sum = 0.f;
@@ -626,9 +629,9 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                     den[u] = sum;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 16);
+                for (int u = 0; u < 2; ++u) den[u] = dvs_add_x16(den[u]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) den[u] += __shfl_xor(den[u], 32);
+                for (int u = 0; u < 2; ++u) den[u] = dvs_add_x32(den[u]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     pT[u] *= (1.0f / den[u]);
@@ -674,9 +677,9 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                     delta[u] = dl;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 16);
+                for (int u = 0; u < 2; ++u) delta[u] = dvs_add_x16(delta[u]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) delta[u] += __shfl_xor(delta[u], 32);
+                for (int u = 0; u < 2; ++u) delta[u] = dvs_add_x32(delta[u]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll

@@ -113,6 +113,21 @@ __device__ __forceinline__ void dvs_lds_barrier() {
 #endif
 }
 
+// Stagger (experiment knob, -DDVS_STAGGER=n: n x 64 cycles): the two waves of a SIMD (one of each wave group) leave a phase's
+// opening barrier in lock-step and run the same instruction stream, so both want the matrix pipe, then both the VALU; the
+// younger wave's FIRST DAG of a phase took 37 k cycles against 22 k once the two had drifted apart (round 1).
+// Holding the younger group back by a fraction of a DAG de-phases them from the start.
+#ifndef DVS_STAGGER
+#define DVS_STAGGER 0
+#endif
+__device__ __forceinline__ void dvs_stagger(int wave) {
+#if !defined(DVS_EMU) && DVS_STAGGER > 0
+    if (wave >= 4) {
+        for (int i = 0; i < DVS_STAGGER / 16; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles per step
+    }
+#endif
+}
+
 #ifdef DVS_EMU
 #define DVS_SCHED_FENCE() ((void)0)
 #else
@@ -288,16 +303,33 @@ __device__ __forceinline__ void dvs_store_tile(float* __restrict__ base, size_t 
 }
 
 // ---- reductions over the 64 features of a token (T-layout: 16 in-lane values x 4 lane groups g) --------------
-__device__ __forceinline__ float dvs_sum_g(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// v[l] + v[l ^ 16] (resp. ^ 32), max likewise: the partner's value through gfx950's v_permlane16_swap / v_permlane32_swap — a
+// VALU operation — instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 (an LDS-crossbar round trip of ~100+ cycles
+// sitting in the softmax / LayerNorm dependency chains: 32 of them per DAG in the attention forward alone, 19 % of its
+// loop by tools/attn_stamps.py).  The swap exchanges the odd 16-lane rows of its first operand with the even rows of the
+// second (32: the upper half with the lower half), so with both operands = v the two results hold {own, partner} in an
+// order that depends on the row — irrelevant to a commutative op, and bitwise the same sum as before.  Inline asm: the
+// builtin (__builtin_amdgcn_permlane16_swap) drops the second result on ROCm 7.2 (it emitted v1 + v1).  s_nop 1: the
+// VALU-write -> permlane-read wait states hipcc inserts for its own permlanes; nothing pads inside an asm statement.
+#ifndef DVS_EMU
+__device__ __forceinline__ void dvs_swap16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float dvs_max_g(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+__device__ __forceinline__ void dvs_swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+__device__ __forceinline__ float dvs_add_x16(float v) { float a = v, b = v; dvs_swap16(a, b); return a + b; }
+__device__ __forceinline__ float dvs_add_x32(float v) { float a = v, b = v; dvs_swap32(a, b); return a + b; }
+__device__ __forceinline__ float dvs_max_x16(float v) { float a = v, b = v; dvs_swap16(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float dvs_max_x32(float v) { float a = v, b = v; dvs_swap32(a, b); return fmaxf(a, b); }
+#else
+__device__ __forceinline__ float dvs_add_x16(float v) { return v + __shfl_xor(v, 16); }
+__device__ __forceinline__ float dvs_add_x32(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float dvs_max_x16(float v) { return fmaxf(v, __shfl_xor(v, 16)); }
+__device__ __forceinline__ float dvs_max_x32(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+#endif
+__device__ __forceinline__ float dvs_sum_g(float v) { return dvs_add_x32(dvs_add_x16(v)); }
+__device__ __forceinline__ float dvs_max_g(float v) { return dvs_max_x32(dvs_max_x16(v)); }
 __device__ __forceinline__ float dvs_sum_r(float v) {   // over the 16 lanes r of one g group
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);

@@ -289,6 +289,16 @@ void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 #ifdef DVS_STAMPS
 DVS_STAMP_DECL(dvs_stamps_fwd);
+// inner budget of the attention forward DAG loop: cycles summed over DAGs and phases, per (workgroup, wave, segment)
+__device__ unsigned long long dvs_stamps_attn[256 * 8 * 8];
+#define ASTAMP(k)                                                                                                   \
+    do {                                                                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                               \
+        if ((dvs_tid() & 63) == 0 && dvs_bid() < 256) dvs_stamps_attn[(dvs_bid() * 8 + (dvs_tid() >> 6)) * 8 + (k)] += now_ - ast_; \
+        ast_ = now_;                                                                                                \
+    } while (0)
+#else
+#define ASTAMP(k) ((void)0)
 #endif
 struct AttnLds {
     dvs_bf16 *Win, *Wout;                     // bf16x6 image triples (dvs_bf16.h); in-projection rows / out-projection columns in slot order
@@ -364,9 +374,9 @@ __device__ __forceinline__ void attn_softmax_T(f4 (&p)[8], float (&m)[8], float 
         m[h] = mx;
     }
 #pragma unroll
-    for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 16));
+    for (int h = 0; h < 8; ++h) m[h] = dvs_max_x16(m[h]);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) m[h] = fmaxf(m[h], __shfl_xor(m[h], 32));
+    for (int h = 0; h < 8; ++h) m[h] = dvs_max_x32(m[h]);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
         float sum = 0.f;
@@ -378,9 +388,9 @@ __device__ __forceinline__ void attn_softmax_T(f4 (&p)[8], float (&m)[8], float 
         den[h] = sum;
     }
 #pragma unroll
-    for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 16);
+    for (int h = 0; h < 8; ++h) den[h] = dvs_add_x16(den[h]);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) den[h] += __shfl_xor(den[h], 32);
+    for (int h = 0; h < 8; ++h) den[h] = dvs_add_x32(den[h]);
 #pragma unroll
     for (int h = 0; h < 8; ++h) p[h] *= (1.0f / den[h]);
 }
@@ -415,10 +425,19 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int N = a.dims.N;
+#ifdef DVS_STAMPS
+    unsigned long long ast_ = __builtin_amdgcn_s_memtime();
+#endif
+    dvs_stagger(L.wave);
     for (int dag = dvs_bid() * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+        ASTAMP(7);
         f4 x[4], dummy[4];
         float rstd;
         dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+#ifdef DVS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ASTAMP(0);
         f4 q[4], k[4], v[4];
         {
             const Split3T xs = dvs_split3_T(x);
@@ -430,6 +449,7 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
                 attn_qkv(q, k, v, xs, xs, l, L);
             }
         }
+        ASTAMP(1);
         const unsigned allowed_r = a.rec[dag].allowed[L.r];
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
@@ -437,8 +457,10 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
         float m[8], den[8];
         attn_scores_T(s, q, k, L);
         attn_softmax_T(p, m, den, s, allowed_r, L);
+        ASTAMP(2);
 #pragma unroll
         for (int h = 0; h < 8; ++h) p[h] = attn_drop_T(p[h], kprob, h, D, L);
+        ASTAMP(3);
         // O^T = V^T P^T per head on all 16 feature rows of the tile; rows reg 0,1 belong to head 2t, rows 2,3 to 2t+1
         f4 o[4];
         {
@@ -455,10 +477,12 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = f4{oa[t][0], oa[t][1], ob[t][2], ob[t][3]};
         }
+        ASTAMP(4);
         f4 y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = dvs_vecT(l.outb, t, L);
         dvs_matb3<4>(y, dvs_split3_T(o), l.Wout, 64, 0, L);
+        ASTAMP(5);
         dvs_dropout_tile(y, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L);
         const bool valid = L.r < N;
 #pragma unroll
@@ -466,6 +490,7 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) y[t][kk] = valid ? x[t][kk] + y[t][kk] : 0.f;
         dvs_store_pre(a.out_pre, a.out_stats, dag, y, L);
+        ASTAMP(6);
     }
     DVS_STAMP(dvs_stamps_fwd, mine, 2);
     if (has_next) {
@@ -542,6 +567,7 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, 
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int ntiles = a.dims.B * a.dims.NT;
+    dvs_stagger(L.wave);
     for (int tile = dvs_bid() * L.nwaves + L.wave; tile < ntiles; tile += gridDim.x * L.nwaves) {
         const DvsTile T = dvs_tile_of(tile, a.dims);
         f4 x[4], dummy[4];
@@ -676,6 +702,15 @@ void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st) {
 }
 
 #ifdef DVS_STAMPS
+extern "C" int dvs_debug_read_stamps_attn(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_attn)) bytes = sizeof(dvs_stamps_attn);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_attn), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_attn)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_attn)) != hipSuccess) return 2;
+    }
+    return 0;
+}
 extern "C" int dvs_debug_read_stamps_fwd(void* out, size_t bytes, int clear) {
     if (bytes > sizeof(dvs_stamps_fwd)) bytes = sizeof(dvs_stamps_fwd);
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_fwd), bytes) != hipSuccess) return 1;

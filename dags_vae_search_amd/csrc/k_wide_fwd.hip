@@ -394,9 +394,9 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                 }
         }
 #pragma unroll
-        for (int it = 0; it < DVS_WNT; ++it) m[it] = fmaxf(m[it], __shfl_xor(m[it], 16));
+        for (int it = 0; it < DVS_WNT; ++it) m[it] = dvs_max_x16(m[it]);
 #pragma unroll
-        for (int it = 0; it < DVS_WNT; ++it) m[it] = fmaxf(m[it], __shfl_xor(m[it], 32));
+        for (int it = 0; it < DVS_WNT; ++it) m[it] = dvs_max_x32(m[it]);
 #pragma unroll
         for (int it = 0; it < DVS_WNT; ++it) {
             den[it] = 0.f;
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                 }
         }
 #pragma unroll
-        for (int it = 0; it < DVS_WNT; ++it) den[it] += __shfl_xor(den[it], 16);
+        for (int it = 0; it < DVS_WNT; ++it) den[it] = dvs_add_x16(den[it]);
 #pragma unroll
-        for (int it = 0; it < DVS_WNT; ++it) den[it] += __shfl_xor(den[it], 32);
+        for (int it = 0; it < DVS_WNT; ++it) den[it] = dvs_add_x32(den[it]);
         f4 o[DVS_WNT];
 #pragma unroll
         for (int it = 0; it < DVS_WNT; ++it) {

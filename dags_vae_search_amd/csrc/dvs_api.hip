@@ -449,6 +449,7 @@ static void prepare_images(const DvsLayout& L, bool wide, const float* params, f
         add(p.in_w, b + DvsAttnImg::Win, 192, wide ? 0 : 2);             // x6
         add(p.out_w, b + DvsAttnImg::Wout, 64, wide ? 0 : 4);            // x6
         add(p.out_w, b + DvsAttnImg::WoutT, 64, 1 | (wide ? 0 : 4));     // x3 transposed
+        add(p.in_w, b + DvsAttnImg::WinB, 192, 16 | (wide ? 0 : 2));     // parts hi, mid again, behind WoutT
         for (int q = 0; q < 3; ++q)                                    // W_q^T, W_k^T, W_v^T for k_proj_bwd
             add(p.in_w + 4096 * q, b + DvsAttnImg::WinT + (size_t)q * 2 * DVS_IMG64, 64, 1 | (wide ? 0 : 2));
     };

@@ -57,11 +57,11 @@ struct AttnBLds {
 };
 DVS_HD inline AttnBLds attnb_lds(char* smem) {
     AttnBLds l;
-    l.Winh = (dvs_bf16*)smem;
-    l.Winl = l.Winh + 192 * DVS_LDB;
-    l.WoTh = l.Winl + 192 * DVS_LDB;
+    l.WoTh = (dvs_bf16*)smem;                  // global order of the block (dvs_wimg.h): WoutT pair, WinB pair
     l.WoTl = l.WoTh + 64 * DVS_LDB;
-    l.inb = (float*)(l.WoTl + 64 * DVS_LDB);
+    l.Winh = l.WoTl + 64 * DVS_LDB;
+    l.Winl = l.Winh + 192 * DVS_LDB;
+    l.inb = (float*)(l.Winl + 192 * DVS_LDB);
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
@@ -95,8 +95,7 @@ DVS_HD inline ProjBLds projb_lds(char* smem, int nproj) {
 inline void ffnb_plan(DvsStagePlan& p, const FfnBwdArgs& a, char* smem) {
     const FfnBLds l = ffnb_lds(smem);
     dvs_plan_clear(p);
-    dvs_plan_seg(p, smem, l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(4 * DVS_IMG64));   // W2^T, W1^T x3 pairs
-    dvs_plan_seg(p, smem, l.W1x6, (const dvs_bf16*)a.wimg + DvsFfnImg::W1, (int)(3 * DVS_IMG64));
+    dvs_plan_seg(p, smem, l.W2Th, (const dvs_bf16*)a.wimg + DvsFfnImg::W2T, (int)(7 * DVS_IMG64));   // W2^T, W1^T x3 pairs, W1 x6
     dvs_plan_vec(p, smem, l.b1, a.l1_b, 64);
     dvs_plan_vec(p, smem, l.b2, a.l2_b, 64);
     dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
@@ -109,8 +108,7 @@ inline void ffnb_plan(DvsStagePlan& p, const FfnBwdArgs& a, char* smem) {
 inline void attnb_plan(DvsStagePlan& p, const AttnBwdArgs& a, char* smem) {
     const AttnBLds l = attnb_lds(smem);
     dvs_plan_clear(p);
-    dvs_plan_seg(p, smem, l.Winh, (const dvs_bf16*)a.wimg + DvsAttnImg::Win, 2 * 192 * DVS_LDB);   // parts hi, mid of the x6 triple = the x3 pair
-    dvs_plan_seg(p, smem, l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));
+    dvs_plan_seg(p, smem, l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(8 * DVS_IMG64));   // Wo^T pair, then parts hi, mid of Win
     dvs_plan_vec(p, smem, l.inb, a.in_b, 192, true);
     dvs_plan_vec(p, smem, l.outb, a.out_b, 64);
     dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
@@ -142,12 +140,12 @@ struct DvsBwdTail {
 };
 template <class PP>
 __device__ __forceinline__ void dvs_tail_issue(DvsBwdTail& t, PP next, bool has_next) {
-    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_issue(t.pf, next, dvs_tid(), DVS_PF_THREADS);
+    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_issue<false>(t.pf, next, dvs_tid(), DVS_PF_THREADS);
 }
 // call after the last LDS access of the epilogue, with a workgroup barrier in between; the caller's next barrier publishes it
 template <class PP>
 __device__ __forceinline__ void dvs_tail_commit(const DvsBwdTail& t, PP next, bool has_next, char* smem) {
-    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_commit(t.pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+    if (has_next && dvs_tid() < DVS_PF_THREADS) dvs_prefetch_commit<false>(t.pf, next, smem, dvs_tid(), DVS_PF_THREADS);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -16,17 +16,20 @@
 #pragma once
 #include "dvs_device.h"
 
-constexpr int DVS_PLAN_SEGS = 2;       // dvs_plan_chunk is written for exactly two
-constexpr int DVS_PLAN_VECS = 6;
+constexpr int DVS_PLAN_VECS = 6;        // <= 8: two units per wave of a 4-wave tail (dvs_prefetch_issue)
 struct DvsStagePlan {
-    const f4* src[DVS_PLAN_SEGS];      // global source of segment s (16-byte aligned)
-    int dst16[DVS_PLAN_SEGS];          // LDS destination, in 16-byte units from the start of dynamic LDS
-    int n16[DVS_PLAN_SEGS];            // length in 16-byte units
-    const float* vsrc[DVS_PLAN_VECS];  // small vectors: element i of vector j goes to LDS float vdst[j] + i
+    const f4* src;                     // global source of the image block (16-byte aligned): ONE contiguous block per phase —
+                                       // dvs_wimg.h lays the per-step images out so that every phase kind finds its own
+    int dst16;                         // LDS destination, in 16-byte units from the start of dynamic LDS
+    int n16;                           // length in 16-byte units, a multiple of 64 (whole 1 KB wave chunks)
+    // small vectors (biases, LayerNorm parameters), cut into units of <= 64 floats: unit j = elements vbase[j] .. vbase[j] + 63
+    // of the vector at vsrc[j] (vlen[j] elements in all, 0: unused unit) -> LDS floats vdst[j] + vbase[j] ..
+    const float* vsrc[DVS_PLAN_VECS];
     int vdst[DVS_PLAN_VECS];
-    int vlen[DVS_PLAN_VECS];           // <= 256 floats
-    int vperm;                         // bit j: vector j is read through dvs_pi (attention slot order)
-    int nseg, nvec;
+    int vbase[DVS_PLAN_VECS];
+    int vlen[DVS_PLAN_VECS];
+    int vperm;                         // bit j: unit j is read through dvs_pi (attention slot order)
+    int nvec;
     int zero_int;                      // LDS int index of two group-barrier counters to clear, or -1
     int phase;                         // index of the phase inside its chained launch (diagnostic stamps, tools/phase_stamps.py)
 };
@@ -56,35 +59,35 @@ constexpr int DVS_STAMP_IDS = 8, DVS_STAMP_PHASES = 32, DVS_STAMP_WAVES = 8, DVS
 #endif
 #define DVS_FAKE_LDS ((char*)(uintptr_t)(1u << 20))      // host-side stand-in for the dynamic-LDS base: only differences are used
 DVS_HD inline void dvs_plan_clear(DvsStagePlan& p) {
-    for (int i = 0; i < DVS_PLAN_SEGS; ++i) {
-        p.src[i] = nullptr;
-        p.dst16[i] = 0;
-        p.n16[i] = 0;
-    }
+    p.src = nullptr;
+    p.dst16 = 0;
+    p.n16 = 0;
     for (int i = 0; i < DVS_PLAN_VECS; ++i) {
         p.vsrc[i] = nullptr;
         p.vdst[i] = 0;
+        p.vbase[i] = 0;
         p.vlen[i] = 0;
     }
     p.phase = 0;
-    p.nseg = 0;
     p.nvec = 0;
     p.vperm = 0;
     p.zero_int = -1;
 }
 DVS_HD inline void dvs_plan_seg(DvsStagePlan& p, const char* smem, const void* lds_dst, const void* src, int n_bf16) {
-    p.src[p.nseg] = (const f4*)src;
-    p.dst16[p.nseg] = (int)(((const char*)lds_dst - smem) >> 4);
-    p.n16[p.nseg] = n_bf16 >> 3;
-    ++p.nseg;
+    p.src = (const f4*)src;
+    p.dst16 = (int)(((const char*)lds_dst - smem) >> 4);
+    p.n16 = n_bf16 >> 3;               // every image is a multiple of 64 rows x 144 bytes = 9 wave chunks
 }
 DVS_HD inline void dvs_plan_vec(DvsStagePlan& p, const char* smem, const float* lds_dst, const float* src, int n,
                                 bool perm = false) {
-    p.vsrc[p.nvec] = src;
-    p.vdst[p.nvec] = (int)(((const char*)lds_dst - smem) >> 2);
-    p.vlen[p.nvec] = n;
-    if (perm) p.vperm |= 1 << p.nvec;
-    ++p.nvec;
+    for (int base = 0; base < n; base += 64) {
+        p.vsrc[p.nvec] = src;
+        p.vdst[p.nvec] = (int)(((const char*)lds_dst - smem) >> 2);
+        p.vbase[p.nvec] = base;
+        p.vlen[p.nvec] = n;
+        if (perm) p.vperm |= 1 << p.nvec;
+        ++p.nvec;
+    }
 }
 
 // Registers of one thread's share of a plan: NCH x 16 bytes of image data and one float per small vector.  In the chained
@@ -98,7 +101,7 @@ constexpr int DVS_PF_BWD = 9, DVS_PF_FWD = 14, DVS_PF_BWD_TAIL = 18, DVS_PF_FWD_
 template <int NCH>
 struct DvsPrefetch {
     f4 v[NCH];
-    float s[DVS_PLAN_VECS];
+    float s[2];                        // vector units wave and wave + #waves (#waves >= 4, DVS_PLAN_VECS <= 8)
 };
 
 // The device functions below take the plan through a pointer type PP: a plain pointer (per-phase kernels: the plan is a
@@ -117,69 +120,98 @@ typedef const DvsStagePlan* DvsPlanK;
 // L2 round trips per phase instead of one batch in flight (measured: the first version of this file, with `if (k < total)
 // v = *src`, made the chained kernels 10-20 % SLOWER than staging behind the barrier).  Only the LDS stores are predicated.
 DVS_HD inline void dvs_plan_seal(DvsStagePlan& p) {
-    for (int i = 0; i < DVS_PLAN_SEGS; ++i)
-        if (i >= p.nseg || !p.src[i]) {
-            p.src[i] = p.src[0];
-            p.n16[i] = 0;
-        }
     for (int i = 0; i < DVS_PLAN_VECS; ++i)
         if (i >= p.nvec || !p.vsrc[i] || p.vlen[i] <= 0) {
-            p.vsrc[i] = (const float*)p.src[0];
+            p.vsrc[i] = (const float*)p.src;
+            p.vbase[i] = 0;
             p.vlen[i] = 0;
         }
 }
 
-// Every workgroup of the launch fetches the SAME images at about the same time: each starts at a different chunk so that
-// they do not all queue on the same L2 lines (dvs_copy_image's rotation).
-__device__ __forceinline__ int dvs_plan_rot(int total) {
-    return (int)(((unsigned)dvs_bid() * 2654435761u) % (unsigned)(total > 0 ? total : 1));
+// The tail of a phase runs on ONE wave per SIMD (the older group), so every instruction costs its full issue latency
+// (~5 cycles) and the INSTRUCTION COUNT of issue + commit is what the critical path pays: the first versions spent 17-20
+// instructions per 16-byte slot on per-lane chunk arithmetic (two segments, rotation, range checks) and took 4.3-8.5 k
+// cycles per phase for the commit alone — as much warm as cold, i.e. neither load latency nor instruction fetch
+// (profiles/r02_phase_stamps.txt).  Now: one segment, work handed out in whole 1 KB WAVE chunks (chunk c -> wave c mod
+// #waves; slot u of a wave is chunk u * #waves + wave), so that liveness, rotation and addresses are scalar arithmetic and a
+// slot costs ~4 instructions in the issue and ~3 in the commit; the small vectors are handed out one unit per wave.
+//  * fields are read as VALUES: `(s1 ? p->dst16[1] : p->dst16[0])` is an lvalue, clang then selects the ADDRESS per lane and
+//    emits a VECTOR load from the kernel-argument segment per slot, each followed by s_waitcnt vmcnt(0) (18-27 serialised
+//    L2 round trips: the 5.7-8.5 k version).
+//  * ROT (first phase of a launch, per-phase kernels): every workgroup of the launch fetches the SAME images at the same
+//    time, each starts at a different chunk so that they do not all queue on the same L2 lines.  Tails are already
+//    de-synchronised by their DAG loops and skip it.
+__device__ __forceinline__ int dvs_uniform(int v) {
+#ifndef DVS_EMU
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
 }
-// chunk k of thread-slot order -> rotated chunk index, source address and LDS float4 index (two segments)
-template <class PP>
-__device__ __forceinline__ void dvs_plan_chunk(PP p, int k, int total, int rot, const f4*& src, int& dst) {
-    const int n0 = p->n16[0];
-    int kr = (k < total ? k : 0) + rot;
-    kr = kr >= total ? kr - total : kr;
-    const bool s1 = kr >= n0;
-    const int off = s1 ? kr - n0 : kr;
-    src = (s1 ? p->src[1] : p->src[0]) + off;
-    dst = (s1 ? p->dst16[1] : p->dst16[0]) + off;
+struct DvsPlanHead {
+    const char* src;
+    int dst, nwc, rot, wave, nw, lane16;
+};
+template <bool ROT, class PP>
+__device__ __forceinline__ DvsPlanHead dvs_plan_head(PP p, int tid, int step) {
+    DvsPlanHead h;
+    h.src = (const char*)p->src;
+    h.dst = p->dst16 * 16;
+    h.nwc = p->n16 >> 6;
+    h.rot = ROT ? (int)(((unsigned)dvs_bid() * 2654435761u) % (unsigned)(h.nwc > 0 ? h.nwc : 1)) : 0;
+    h.wave = dvs_uniform(tid >> 6);
+    h.nw = step >> 6;
+    h.lane16 = (tid & 63) * 16;
+    return h;
+}
+// slot u of this wave -> chunk (live or not) and its byte offset inside the block
+template <bool ROT>
+__device__ __forceinline__ bool dvs_plan_slot(const DvsPlanHead& h, int u, int& byte) {
+    int c = u * h.nw + h.wave;
+    const bool live = c < h.nwc;
+    if (ROT) {
+        c += h.rot;
+        c = c >= h.nwc ? c - h.nwc : c;
+    }
+    byte = ((live ? c : 0) << 10) + h.lane16;
+    return live;
 }
 
-// tid / step: index of this thread among the `step` threads that share the plan (the whole workgroup, or its first
-// DVS_PF_THREADS threads in a chained kernel's tail; callers keep the other threads out)
-template <int NCH, class PP>
+// tid / step: index of this thread among the `step` threads (a multiple of 64) that share the plan — the whole workgroup, or
+// its first DVS_PF_THREADS threads in a chained kernel's tail; callers keep the other threads out
+template <bool ROT, int NCH, class PP>
 __device__ __forceinline__ void dvs_prefetch_issue(DvsPrefetch<NCH>& pf, PP p, int tid, int step) {
-    const int total = p->n16[0] + p->n16[1], rot = dvs_plan_rot(total);
+    const DvsPlanHead h = dvs_plan_head<ROT>(p, tid, step);
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
-        const f4* src;
-        int dst;
-        dvs_plan_chunk(p, tid + u * step, total, rot, src, dst);
-        pf.v[u] = *src;
+        int byte;
+        dvs_plan_slot<ROT>(h, u, byte);
+        pf.v[u] = *(const f4*)(h.src + (unsigned)byte);
     }
+    // vector units: wave w fetches units w and w + #waves (uniform index into the plan: scalar loads), every load unconditional
 #pragma unroll
-    for (int j = 0; j < DVS_PLAN_VECS; ++j) {
-        const int len = p->vlen[j];
-        const int idx = tid < len ? tid : 0;
-        pf.s[j] = p->vsrc[j][((p->vperm >> j) & 1) ? dvs_pi(idx) : idx];
+    for (int q = 0; q < 2; ++q) {
+        const int j = h.wave + q * h.nw, jc = j < DVS_PLAN_VECS ? j : 0;
+        const int idx = p->vbase[jc] + (tid & 63);
+        const int ic = (j < DVS_PLAN_VECS && idx < p->vlen[jc]) ? idx : 0;
+        pf.s[q] = p->vsrc[jc][((p->vperm >> jc) & 1) ? dvs_pi(ic) : ic];
     }
 }
-template <int NCH, class PP>
+template <bool ROT, int NCH, class PP>
 __device__ __forceinline__ void dvs_prefetch_commit(const DvsPrefetch<NCH>& pf, PP p, char* smem, int tid, int step) {
-    const int total = p->n16[0] + p->n16[1], rot = dvs_plan_rot(total);
-    f4* lds = (f4*)smem;
+    const DvsPlanHead h = dvs_plan_head<ROT>(p, tid, step);
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
-        const f4* src;
-        int dst;
-        dvs_plan_chunk(p, tid + u * step, total, rot, src, dst);
-        if (tid + u * step < total) lds[dst] = pf.v[u];
+        int byte;
+        if (dvs_plan_slot<ROT>(h, u, byte)) *(f4*)(smem + h.dst + byte) = pf.v[u];
     }
     float* ldsf = (float*)smem;
 #pragma unroll
-    for (int j = 0; j < DVS_PLAN_VECS; ++j)
-        if (tid < p->vlen[j]) ldsf[p->vdst[j] + tid] = pf.s[j];
+    for (int q = 0; q < 2; ++q) {
+        const int j = h.wave + q * h.nw, jc = j < DVS_PLAN_VECS ? j : 0;
+        const int idx = p->vbase[jc] + (tid & 63);
+        if (j < DVS_PLAN_VECS && idx < p->vlen[jc]) ldsf[p->vdst[jc] + idx] = pf.s[q];
+    }
     if (p->zero_int >= 0 && tid < 2) ((int*)smem)[p->zero_int + tid] = 0;
 }
 // Stage a plan right away (first phase of a launch, per-phase launches): all loads in flight, then the stores.  The plan
@@ -187,6 +219,6 @@ __device__ __forceinline__ void dvs_prefetch_commit(const DvsPrefetch<NCH>& pf, 
 template <int NCH, class PP>
 __device__ __forceinline__ void dvs_stage_now(PP p, char* smem) {
     DvsPrefetch<NCH> pf;
-    dvs_prefetch_issue(pf, p, dvs_tid(), (int)blockDim.x);
-    dvs_prefetch_commit(pf, p, smem, dvs_tid(), (int)blockDim.x);
+    dvs_prefetch_issue<true>(pf, p, dvs_tid(), (int)blockDim.x);
+    dvs_prefetch_commit<true>(pf, p, smem, dvs_tid(), (int)blockDim.x);
 }

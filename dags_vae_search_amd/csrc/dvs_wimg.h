@@ -9,9 +9,10 @@
 //   attention block : Win  x6 [3][192][LDB]  rows in slot order         (k_attn_fwd; parts 0,1 = the x3 pair of k_attn_bwd)
 //                     Wout x6 [3][ 64][LDB]  columns in slot order      (k_attn_fwd)
 //                     WoutT x3 [2][64][LDB]  image rows in slot order   (k_attn_bwd: dO^T = Wo^T dy^T)
+//                     WinB  x3 [2][192][LDB] = parts 0, 1 of Win again   (k_attn_bwd: q, k, v recompute)
 //                     WinT  x3 [3 proj][2][64][LDB]                     (k_proj_bwd: dX^T = W_p^T dY_p^T)
-//   FFN block       : W1 x6 [3][64][LDB], W2 x6 [3][64][LDB]            (k_ffn_fwd; W1 also k_ffn_bwd's hidden recompute)
-//                     W2T x3 [2][64][LDB], W1T x3 [2][64][LDB]          (k_ffn_bwd)
+//   FFN block       : W2T x3 [2][64][LDB], W1T x3 [2][64][LDB]          (k_ffn_bwd)
+//                     W1 x6 [3][64][LDB], W2 x6 [3][64][LDB]            (k_ffn_fwd; W1 also k_ffn_bwd's hidden recompute)
 //   loss block      : Wa, Wb x6 [3][64][LDB] each (the two 64-column halves of add_edge.0.weight: k_loss_fwd and
 //                     k_loss_bwd's recompute — the sign of Wa h_i + Wb h_j + b is a ReLU mask, so both use the same
 //                     bf16x6 sequence), WaT, WbT x3 [2][64][LDB] (k_loss_bwd: d h)
@@ -19,18 +20,23 @@
 #include "dvs_bf16.h"
 
 constexpr size_t DVS_IMG64 = 64 * (size_t)DVS_LDB;            // one 64-row image
+// Every phase stages ONE contiguous block (dvs_stage.h): [Win, Wout] the attention forward, [WoutT, WinB] the attention-core
+// backward (WinB: a second copy of parts hi, mid of Win — 55 KB more per attention and step for k_prepare_images, against a
+// two-segment copy in every backward tail), WinT pairs the projection backward; [W2T, W1T, W1] the FFN backward, [W1, W2] the
+// FFN forward.
 struct DvsAttnImg {
     static constexpr size_t Win = 0;
     static constexpr size_t Wout = 3 * 3 * DVS_IMG64;
     static constexpr size_t WoutT = Wout + 3 * DVS_IMG64;
-    static constexpr size_t WinT = WoutT + 2 * DVS_IMG64;
+    static constexpr size_t WinB = WoutT + 2 * DVS_IMG64;
+    static constexpr size_t WinT = WinB + 2 * 3 * DVS_IMG64;
     static constexpr size_t SIZE = WinT + 3 * 2 * DVS_IMG64;
 };
 struct DvsFfnImg {
-    static constexpr size_t W1 = 0;
-    static constexpr size_t W2 = 3 * DVS_IMG64;
-    static constexpr size_t W2T = 6 * DVS_IMG64;
-    static constexpr size_t W1T = 8 * DVS_IMG64;
+    static constexpr size_t W2T = 0;
+    static constexpr size_t W1T = 2 * DVS_IMG64;
+    static constexpr size_t W1 = 4 * DVS_IMG64;
+    static constexpr size_t W2 = 7 * DVS_IMG64;
     static constexpr size_t SIZE = 10 * DVS_IMG64;
 };
 struct DvsLossImg {
@@ -49,7 +55,7 @@ struct DvsImgJob {
     int64_t src;                 // float offset of the matrix in the flat parameter buffer
     int64_t dst;                 // bf16 offset of the image (first part) in the image buffer
     int32_t rows;                // source rows (64 columns)
-    int32_t flags;               // bit 0: transposed x3 (else x6 rows); bit 1: rperm; bit 2: cperm; bit 3: source rows are 128 floats apart
+    int32_t flags;               // bit 0: transposed x3 (else x6 rows); bit 1: rperm; bit 2: cperm; bit 3: source rows are 128 floats apart; bit 4: x6 rows, parts 0 and 1 only
 };
 constexpr int DVS_MAX_IMG_JOBS = 96;
 struct DvsImgJobs {

@@ -497,12 +497,22 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
         // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
         DvsPrefetch<DVS_PF_FWD_TAIL> pf;
         const bool fetcher = dvs_tid() < DVS_PF_THREADS;
-        if (fetcher) dvs_prefetch_issue(pf, next, dvs_tid(), DVS_PF_THREADS);
+        if (fetcher) dvs_prefetch_issue<false>(pf, next, dvs_tid(), DVS_PF_THREADS);
         DVS_STAMP(dvs_stamps_fwd, mine, 3);
         dvs_lds_barrier();               // every wave is done with this phase's images
         DVS_STAMP(dvs_stamps_fwd, mine, 4);
-        if (fetcher) dvs_prefetch_commit(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+#ifdef DVS_STAMPS_ICACHE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DVS_STAMP(dvs_stamps_fwd, mine, 5);
+#endif
+        if (fetcher) dvs_prefetch_commit<false>(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
         DVS_STAMP(dvs_stamps_fwd, mine, 6);
+#ifdef DVS_STAMPS_ICACHE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (fetcher) dvs_prefetch_commit<false>(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DVS_STAMP(dvs_stamps_fwd, mine, 7);
+#endif
     }
 }
 
@@ -616,12 +626,22 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, 
         // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
         DvsPrefetch<DVS_PF_FWD_TAIL> pf;
         const bool fetcher = dvs_tid() < DVS_PF_THREADS;
-        if (fetcher) dvs_prefetch_issue(pf, next, dvs_tid(), DVS_PF_THREADS);
+        if (fetcher) dvs_prefetch_issue<false>(pf, next, dvs_tid(), DVS_PF_THREADS);
         DVS_STAMP(dvs_stamps_fwd, mine, 3);
         dvs_lds_barrier();               // every wave is done with this phase's images
         DVS_STAMP(dvs_stamps_fwd, mine, 4);
-        if (fetcher) dvs_prefetch_commit(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+#ifdef DVS_STAMPS_ICACHE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DVS_STAMP(dvs_stamps_fwd, mine, 5);
+#endif
+        if (fetcher) dvs_prefetch_commit<false>(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
         DVS_STAMP(dvs_stamps_fwd, mine, 6);
+#ifdef DVS_STAMPS_ICACHE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (fetcher) dvs_prefetch_commit<false>(pf, next, smem, dvs_tid(), DVS_PF_THREADS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DVS_STAMP(dvs_stamps_fwd, mine, 7);
+#endif
     }
 }
 

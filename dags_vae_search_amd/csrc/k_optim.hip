@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
             const size_t o = (size_t)row * DVS_LDB + dvs_kperm(col), part = (size_t)J.rows * DVS_LDB;
             dst[o] = h;
             dst[part + o] = m;
-            dst[2 * part + o] = l;
+            if (!(J.flags & 16)) dst[2 * part + o] = l;
         } else {                                 // x3 transposed: [2][64][LDB], img[col][kperm(row)]
             dvs_bf16 h, l;
             dvs_split1(v, h, l);

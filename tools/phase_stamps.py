@@ -71,7 +71,9 @@ def main():
             base = e5 if e5[:, 0].any() else a4
             commit = m(c6[:, 0] - base[:, 0]) if c6[:, 0].any() else 0.0
             total = m(nxt[:, 0] - e0[:, 0]) if nxt is not None else 0.0
-            print(f"{ph:5d} {stage:7.0f} {loop_o:9.0f} {loop_y:8.0f} {issue:7.0f} {wa_o:11.0f} {wa_y:9.0f} {epi:7.0f} {commit:7.0f} {total:7.0f}")
+            again = m(t[:, 0, ph, 7] - c6[:, 0]) if t[:, 0, ph, 7].any() else 0.0      # DVS_STAMPS_ICACHE builds only
+            print(f"{ph:5d} {stage:7.0f} {loop_o:9.0f} {loop_y:8.0f} {issue:7.0f} {wa_o:11.0f} {wa_y:9.0f} {epi:7.0f} {commit:7.0f} {total:7.0f}"
+                  + (f"   commit repeated: {again:6.0f}" if again else ""))
 
 
 if __name__ == "__main__":

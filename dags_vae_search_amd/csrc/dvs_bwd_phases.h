@@ -15,6 +15,22 @@ static size_t projb_lds_bytes(int nproj) {
 
 #include "dvs_stage.h"
 
+// Epilogue scratch (the older wave group's partial weight gradients and the vector sums, handed to the younger group through
+// LDS) starts at a FIXED offset above everything a staging plan writes — images, small vectors, group counters of ANY backward
+// phase kind — so that the older group can commit the next phase's plan while the younger group is still flushing this
+// phase's gradients: one workgroup barrier and the whole commit (2.2-5.8 k cycles) off the critical path of every phase.
+// At this point of a phase the per-wave slots that live there are dead (the DAG loop is over).
+constexpr size_t DVS_BWD_EPI_FLOOR = 80 * 1024;
+static_assert(8 * DVS_IMG64 * sizeof(dvs_bf16) + (192 + 64 + 128) * 4 + 16 <= DVS_BWD_EPI_FLOOR, "attention-core plan");
+static_assert(7 * DVS_IMG64 * sizeof(dvs_bf16) + 6 * 64 * 4 + 16 <= DVS_BWD_EPI_FLOOR, "FFN plan");
+static_assert(6 * DVS_IMG64 * sizeof(dvs_bf16) + 128 * 4 + 16 <= DVS_BWD_EPI_FLOOR, "projection plan");
+// ... and ends inside the phase's own LDS footprint (matrices of 4096 floats, then [8 waves][k][64] vector partials)
+static_assert(DVS_BWD_EPI_FLOOR + (2 * 4096 + 8 * 6 * 64) * 4 <= 7 * DVS_IMG64 * sizeof(dvs_bf16) + (6 * 64 + 8 * 2 * DVS_SCR) * 4, "FFN");
+static_assert(DVS_BWD_EPI_FLOOR + (4096 + 8 * 64) * 4 <= 8 * DVS_IMG64 * sizeof(dvs_bf16) + (384 + 8 * 2 * DVS_SCR) * 4, "attention core");
+static_assert(DVS_BWD_EPI_FLOOR + (1 * 4096 + 8 * 3 * 64) * 4 <= 2 * DVS_IMG64 * sizeof(dvs_bf16) + 8 * DVS_PROJB_SLOT * sizeof(dvs_bf16), "1 projection");
+static_assert(DVS_BWD_EPI_FLOOR + (3 * 4096 + 8 * 5 * 64) * 4 <= 6 * DVS_IMG64 * sizeof(dvs_bf16) + 8 * DVS_PROJB_SLOT * sizeof(dvs_bf16), "3 projections");
+__device__ __forceinline__ float* dvs_bwd_epi(char* smem) { return (float*)(smem + DVS_BWD_EPI_FLOOR); }
+
 #ifdef DVS_STAMPS
 DVS_STAMP_DECL(dvs_stamps_bwd);
 #endif
@@ -26,6 +42,7 @@ struct FfnBLds {
     // The weight gradients run on the bf16 pipe too (dvs_coop_dw_bf: parked bf16 tiles, transposing LDS reads).
     dvs_bf16 *W2Th, *W2Tl, *W1Th, *W1Tl, *W1x6;
     float *b1, *b2, *lg, *lb, *og, *ob, *slots;
+    int* gcount;
 };
 DVS_HD inline FfnBLds ffnb_lds(char* smem) {
     FfnBLds l;
@@ -40,7 +57,8 @@ DVS_HD inline FfnBLds ffnb_lds(char* smem) {
     l.lb = l.lg + 64;
     l.og = l.lb + 64;
     l.ob = l.og + 64;
-    l.slots = l.ob + 64;
+    l.gcount = (int*)(l.ob + 64);              // group-barrier counters: below DVS_BWD_EPI_FLOOR in every layout (see there)
+    l.slots = (float*)(l.gcount + 4);
     return l;
 }
 static size_t ffnb_lds_bytes() {
@@ -65,9 +83,9 @@ DVS_HD inline AttnBLds attnb_lds(char* smem) {
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
-    l.slots = l.lb + 64;                       // per wave: A (d y, row-major) and B (transpose scratch, then O)
+    l.gcount = (int*)(l.lb + 64);
+    l.slots = (float*)(l.gcount + 4);          // per wave: A (d y, row-major) and B (transpose scratch, then O)
     l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
-    l.gcount = (int*)(l.stats + 8 * 128);
     return l;
 }
 static size_t attnb_lds_floats() {
@@ -86,8 +104,8 @@ DVS_HD inline ProjBLds projb_lds(char* smem, int nproj) {
     l.WT = (dvs_bf16*)smem;
     l.lg = (float*)(l.WT + nproj * 2 * DVS_IMG64);
     l.lb = l.lg + 64;
-    l.slots = (dvs_bf16*)(l.lb + 64);
-    l.gcount = (int*)(l.slots + 8 * DVS_PROJB_SLOT);
+    l.gcount = (int*)(l.lb + 64);
+    l.slots = (dvs_bf16*)(l.gcount + 4);
     return l;
 }
 
@@ -102,7 +120,7 @@ inline void ffnb_plan(DvsStagePlan& p, const FfnBwdArgs& a, char* smem) {
     dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
     dvs_plan_vec(p, smem, l.og, a.own.g, a.own_pre ? 64 : 0);
     dvs_plan_vec(p, smem, l.ob, a.own.b, a.own_pre ? 64 : 0);
-    p.zero_int = (int)(((const char*)(l.slots + 8 * 2 * DVS_SCR) - smem) >> 2);
+    p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
     dvs_plan_seal(p);
 }
 inline void attnb_plan(DvsStagePlan& p, const AttnBwdArgs& a, char* smem) {
@@ -170,7 +188,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         __syncthreads();
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 1);
-    int* gcount = (int*)(l.slots + 8 * 2 * DVS_SCR);
+    int* gcount = l.gcount;
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int B = a.dims.B * a.dims.NT;                    // tiles (dvs_tile_of): the sublayer is token-local
@@ -270,7 +288,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     dvs_lds_barrier();
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
-    float* const buf1 = (float*)smem;                  // one 64 x 64 staging buffer per matrix, then the vector sums
+    float* const buf1 = dvs_bwd_epi(smem);             // one 64 x 64 staging buffer per matrix, then the vector sums
     float* const buf2 = buf1 + 4096;
     float* red = buf2 + 4096;                         // [8 waves][6][64]
     dvs_coop_stage(buf1, aW1, L);
@@ -300,8 +318,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         if (off >= 0) slab[off + f] = s;
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
-    dvs_lds_barrier();
-    dvs_tail_commit(tail, next, has_next, smem);
+    dvs_tail_commit(tail, next, has_next, smem);       // below DVS_BWD_EPI_FLOOR: does not touch what the flush still reads
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }
 
@@ -406,7 +423,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
     const bool so = a.slot_order != 0;
-    float* const bufs = (float*)smem;                  // NPROJ staging buffers of 4096 floats, then the vector sums
+    float* const bufs = dvs_bwd_epi(smem);             // NPROJ staging buffers of 4096 floats, then the vector sums
 #pragma unroll
     for (int p = 0; p < NPROJ; ++p) dvs_coop_stage(bufs + 4096 * p, aW[p], L);
     float* red = bufs + 4096 * NPROJ;                 // [8 waves][NPROJ + 2][64]
@@ -433,7 +450,6 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
         else if (a.o_ln_g >= 0) slab[(k == NPROJ ? a.o_ln_g : a.o_ln_b) + f] = s;
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
-    dvs_lds_barrier();
     dvs_tail_commit(tail, next, has_next, smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }
@@ -756,7 +772,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     dvs_lds_barrier();
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
-    float* const bufo = (float*)smem;
+    float* const bufo = dvs_bwd_epi(smem);
     float* red = bufo + 4096;
     dvs_coop_stage(bufo, aWo, L);
     red[L.wave * 64 + L.lane] = 0.f;
@@ -773,7 +789,6 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         slab[a.o_out_b + dvs_tid()] = s;
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
-    dvs_lds_barrier();
     dvs_tail_commit(tail, next, has_next, smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
 }

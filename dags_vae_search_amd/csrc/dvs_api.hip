@@ -255,6 +255,7 @@ DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab) {
     w.slabs = take((size_t)nslab * (size_t)P);
     w.fcpart = take((size_t)DVS_FC_PARTS * (size_t)P);
     w.wimg = take((DVS_WIMG_BF16 + 1) / 2);
+    w.limg = take(DvsLatImg::floats(NT));
     w.total_floats = off;
     return w;
 }
@@ -431,7 +432,7 @@ static inline int blk_dec_cross(int layer) { return 4 + 2 * layer; }
 static inline int blk_enc_ffn(int layer) { return layer; }
 static inline int blk_dec_ffn(int layer) { return 3 + layer; }
 
-static void prepare_images(const DvsLayout& L, bool wide, const float* params, float* ws, const DvsWorkspace& W,
+static void prepare_images(const DvsLayout& L, int N, bool wide, const float* params, float* ws, const DvsWorkspace& W,
                            dvs_stream_t st) {
     DvsImgJobs J;
     J.count = 0;
@@ -473,7 +474,15 @@ static void prepare_images(const DvsLayout& L, bool wide, const float* params, f
         add(L.edge0_w, DVS_WIMG_LOSS + DvsLossImg::WaT, 64, 8 | 1);
         add(L.edge0_w + 64, DVS_WIMG_LOSS + DvsLossImg::WbT, 64, 8 | 1);
     }
-    dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), st);
+    DvsLatImgArgs lat;
+    lat.fc1_w = params + L.fc1_w;
+    lat.fc2_w = params + L.fc2_w;
+    lat.fc3_w = params + L.fc3_w;
+    lat.fc3_b = params + L.fc3_b;
+    lat.img = ws + W.limg;
+    lat.N = N;
+    lat.NT = (N + 15) / 16;
+    dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), lat, st);
 }
 static inline const void* wimg_attn(const float* ws, const DvsWorkspace& W, int block) {
     return (const dvs_bf16*)(ws + W.wimg) + img_attn(block);
@@ -621,6 +630,7 @@ static LatentArgs latent_args(const DvsDims& d, const DvsLayout& L, const DvsWor
     a.fc2_b = P + L.fc2_b;
     a.fc3_w = P + L.fc3_w;
     a.fc3_b = P + L.fc3_b;
+    a.limg = ws + W.limg;
     a.eps_in = eps;
     a.mu = ws + W.mu;
     a.logvar = ws + W.logvar;
@@ -735,7 +745,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t 
     dvs_stream_t st = (dvs_stream_t)stream;
     const FwdGrids grid = fwd_grids(d, is_wide(s));
 
-    prepare_images(L, grid.wide, params, ws, W, st);
+    prepare_images(L, d.N, grid.wide, params, ws, W, st);
     const bool fused_dec_embed = d.drop.on && !grid.wide;
     encoder_forward(d, L, W, rec, params, ws, grid, st, fused_dec_embed);
     dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
@@ -790,7 +800,7 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, size_t record
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
-    prepare_images(L, is_wide(s), params, ws, W, st);
+    prepare_images(L, d.N, is_wide(s), params, ws, W, st);
     encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st);
     LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
     la.dims.training = 0;
@@ -828,7 +838,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, int64_t n_par
     const FwdGrids grid = fwd_grids(d, wide);
     const DvsRecord* rec = (const DvsRecord*)records;
 
-    prepare_images(L, wide, params, ws, W, st);
+    prepare_images(L, d.N, wide, params, ws, W, st);
     dvs_launch_decode_memory(d, z, params + L.fc3_w, params + L.fc3_b, ws + W.mem, st);
     DecodeArgs a;
     memset(&a, 0, sizeof(a));

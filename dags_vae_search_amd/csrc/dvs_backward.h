@@ -62,7 +62,7 @@ struct LatentBwdArgs {
     DvsDims dims;
     const float* gmem;           // d memory [B][1024]
     const float *mu, *logvar, *epsv;
-    const float *fc1_w, *fc2_w, *fc3_w;
+    const float* limg;           // latent weight images of this step (dvs_wimg.h: DvsLatImg), written by the forward
     const float* gcoef;
     float* gz;                   // [B][64] = d mu | d logvar
     float* genc;                 // [B][1024] d enc_out

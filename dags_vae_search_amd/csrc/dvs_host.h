@@ -61,6 +61,7 @@ struct DvsWorkspace {
     size_t slabs;               // [nslab][P] per-workgroup partial parameter gradients
     size_t fcpart;              // [DVS_FC_PARTS][P] partial fc1/fc2/fc3 gradients
     size_t wimg;                // per-step weight images (dvs_wimg.h), bf16, written by the forward entry points
+    size_t limg;                // per-step latent weight images (dvs_wimg.h: DvsLatImg), fp32, contraction index in frag order
     size_t total_floats;
     int nslab;
 };

@@ -71,6 +71,7 @@ struct LatentArgs {
     DvsDims dims;
     const float* xenc;           // [B][1024] LayerNorm'ed encoder output, frag order
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
+    const float* limg;           // latent weight images of this step (dvs_wimg.h: DvsLatImg)
     const float* eps_in;         // optional [B][32], already scaled
     float *mu, *logvar, *z, *epsv;   // [B][32]
     float* mem;                  // [B][1024] frag order (null: encode only)

@@ -51,6 +51,26 @@ constexpr int DVS_N_ATTN_BLOCKS = 9, DVS_N_FFN_BLOCKS = 6;
 constexpr size_t DVS_WIMG_LOSS = DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + DVS_N_FFN_BLOCKS * DvsFfnImg::SIZE;
 constexpr size_t DVS_WIMG_BF16 = DVS_WIMG_LOSS + DvsLossImg::SIZE;
 
+// Latent block (fc1 / fc2 / fc3; k_latent_fwd, k_latent_bwd): fp32 images whose contraction / row index is the FRAG-ORDER
+// position k' of the DAG's activation tiles (k' -> token 16 tile + r', feature 16 t + 4 g' + kk; zero where the token is beyond
+// N), in both orientations, so that an MFMA operand is ONE 16-byte load per lane and a wave's loads are contiguous rows.  The
+// kernels used to read the parameters in place: 64 scattered 16-byte (or 4-byte) pieces per wave load, every 128-byte line
+// fetched by four different waves of a workgroup — 250 MB of L2 reads per launch for 0.37 MB of weights.
+struct DvsLatImg {
+    // K = 1024 * NT.  A: [64 o][K] rows 0-31 fc1, 32-63 fc2;  AT: [K][64];  W3: [K][32] fc3 rows;  W3T: [32][K];  B3: [K] fc3 bias
+    static constexpr size_t A(int) { return 0; }
+    static constexpr size_t AT(int NT) { return (size_t)64 * 1024 * NT; }
+    static constexpr size_t W3(int NT) { return (size_t)128 * 1024 * NT; }
+    static constexpr size_t W3T(int NT) { return (size_t)160 * 1024 * NT; }
+    static constexpr size_t B3(int NT) { return (size_t)192 * 1024 * NT; }
+    static constexpr size_t floats(int NT) { return (size_t)193 * 1024 * NT; }
+};
+struct DvsLatImgArgs {
+    const float *fc1_w, *fc2_w, *fc3_w, *fc3_b;      // parameter order: [32][N*64], [32][N*64], [N*64][32], [N*64]
+    float* img;
+    int N, NT;
+};
+
 struct DvsImgJob {
     int64_t src;                 // float offset of the matrix in the flat parameter buffer
     int64_t dst;                 // bf16 offset of the image (first part) in the image buffer
@@ -62,7 +82,7 @@ struct DvsImgJobs {
     DvsImgJob job[DVS_MAX_IMG_JOBS];
     int count;
 };
-void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, dvs_stream_t st);
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat, dvs_stream_t st);
 
 // LDS <- global image copy, 16 bytes per lane (n = bf16 count, a multiple of 8; both 16-byte aligned).  Loads are issued
 // in batches of 8 per thread before the first store: a load -> store loop pays one full L2 round trip per iteration

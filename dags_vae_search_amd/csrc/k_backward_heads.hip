@@ -386,7 +386,6 @@ __global__ __launch_bounds__(64 * LATB_WAVES) void k_latent_bwd(LatentBwdArgs a)
     __shared__ f4 part[LATB_WAVES][2][64];
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
-    const int ldw = N * 64;
     const float gkl = a.gcoef[1];
     const int dag = blockIdx.x * 16 + L.r;
     const bool dvalid = dag < B;
@@ -394,19 +393,16 @@ __global__ __launch_bounds__(64 * LATB_WAVES) void k_latent_bwd(LatentBwdArgs a)
     const size_t dstride = (size_t)NT * DVS_TILE;
     const int m0 = mch * L.wave;
     f4 dz[2] = {f4_zero(), f4_zero()};
-#pragma unroll 4
+    const int K = 1024 * NT;
+    // d z^T = fc3^T d mem^T: A = row 16 t + r of the transposed fc3 image, contraction positions 16 m + 4 g .. + 3
+    const float* const w3t = a.limg + DvsLatImg::W3T(NT) + (size_t)L.r * K + 4 * L.g;
+#pragma unroll 8
     for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi, mm = m & 63;
-        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
-        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
-        const bool tv = tok < N;
+        const int m = m0 + mi;
         const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
-        const float* wp = a.fc3_w + (size_t)((tv ? tok : 0) * 64 + fb) * 32 + L.r;
         f4 wa[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wa[t][kk] = tv ? wp[kk * 32 + 16 * t] : 0.f;
+        for (int t = 0; t < 2; ++t) wa[t] = *(const f4*)(w3t + (size_t)16 * t * K + 16 * m);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -441,22 +437,15 @@ __global__ __launch_bounds__(64 * LATB_WAVES) void k_latent_bwd(LatentBwdArgs a)
             *(f4*)(a.gz + (size_t)dag * 64 + 32 + 16 * t + 4 * L.g) = dout[t + 2];
         }
     }
-    // d enc_out^T[k'][dag] = sum_o Wfc[o][col(k')] dout^T[o][dag]
-#pragma unroll 2
+    // d enc_out^T[k'][dag] = sum_o Wfc[o][k'] dout^T[o][dag]: A = rows 16 m + r of the transposed [fc1; fc2] image (256 bytes each)
+    const float* const wat = a.limg + DvsLatImg::AT(NT) + (size_t)L.r * 64 + 4 * L.g;
+#pragma unroll 4
     for (int mi = 0; mi < mch; ++mi) {
         const int m = m0 + mi, mm = m & 63;
-        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
         const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
-        const int tokA = 16 * (m >> 6) + 4 * (mm & 3) + (L.r >> 2);
-        const bool av = tokA < N;
-        const size_t colA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
         f4 wa[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float* wp = (t < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (t & 1) + 4 * L.g) * ldw + colA;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wa[t][kk] = av ? wp[(size_t)kk * ldw] : 0.f;
-        }
+        for (int t = 0; t < 4; ++t) wa[t] = *(const f4*)(wat + (size_t)16 * m * 64 + 16 * t);
         f4 o0 = f4_zero(), o1 = f4_zero();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(64 * LAT_WAVES) void k_latent_fwd(LatentArgs a) {
     f4 (*part)[4][64] = (f4 (*)[4][64])smem;            // [LAT_WAVES][4][64]
     const Lane L = dvs_lane();
     const int B = a.dims.B, N = a.dims.N;
-    const int ldw = N * 64;
     const int grp = blockIdx.x;
     const int dag = grp * 16 + L.r;
     const bool dvalid = dag < B;
@@ -33,20 +32,16 @@ __global__ __launch_bounds__(64 * LAT_WAVES) void k_latent_fwd(LatentArgs a) {
     const int NT = a.dims.NT, mch = 64 * NT / LAT_WAVES;
     const size_t dstride = (size_t)NT * DVS_TILE;
     const int m0 = mch * L.wave;
-#pragma unroll 4
+    const int K = 1024 * NT;
+    // A operand: row 16 ot + r of the [fc1; fc2] image, contraction positions 16 m + 4 g .. + 3 (frag order, as the activations)
+    const float* const wrow = a.limg + DvsLatImg::A(NT) + (size_t)L.r * K + 4 * L.g;
+#pragma unroll 8
     for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi, mm = m & 63;
-        const int tok = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
-        const int f0 = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
-        const bool tv = tok < N;
+        const int m = m0 + mi;
         const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
-        const int col = (tv ? tok : 0) * 64 + f0;
         f4 wa[4];
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            const float* wp = (ot < 2 ? a.fc1_w : a.fc2_w) + (size_t)(16 * (ot & 1) + L.r) * ldw + col;
-            wa[ot] = tv ? *(const f4*)wp : f4_zero();
-        }
+        for (int ot = 0; ot < 4; ++ot) wa[ot] = *(const f4*)(wrow + (size_t)16 * ot * K + 16 * m);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -94,18 +89,17 @@ __global__ __launch_bounds__(64 * LAT_WAVES) void k_latent_fwd(LatentArgs a) {
     kl = dvs_sum_g(kl);
     if (L.wave == 0 && L.g == 0 && dvalid && a.dag_loss) a.dag_loss[(size_t)dag * 2 + 1] = kl;
     if (!a.mem) return;
-#pragma unroll 4
+    // mem^T chunk m (rows k' = 16 m ..): A = fc3 image rows (one 128-byte row per lane r, 16 bytes per (t, g)), bias in place
+    const float* const w3 = a.limg + DvsLatImg::W3(NT) + (size_t)L.r * 32 + 4 * L.g;
+    const float* const b3 = a.limg + DvsLatImg::B3(NT) + 4 * L.g;
+#pragma unroll 8
     for (int mi = 0; mi < mch; ++mi) {
         const int m = m0 + mi, mm = m & 63;
-        const int fb = 16 * (mm >> 4) + 4 * ((mm >> 2) & 3);
         const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;            // token of this lane's 4 result rows
-        const int tokA = 16 * (m >> 6) + 4 * (mm & 3) + (L.r >> 2);     // token of this lane's A row
-        const bool av = tokA < N;
-        const size_t rowA = (size_t)(av ? tokA : 0) * 64 + fb + (L.r & 3);
-        f4 o = tokD < N ? *(const f4*)(a.fc3_b + tokD * 64 + fb) : f4_zero();
+        f4 o = *(const f4*)(b3 + 16 * m);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f4 wa = av ? *(const f4*)(a.fc3_w + rowA * 32 + 16 * t + 4 * L.g) : f4_zero();
+            const f4 wa = *(const f4*)(w3 + (size_t)16 * m * 32 + 16 * t);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(wa[kk], z[t][kk], o);
         }

@@ -73,9 +73,58 @@ void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, floa
 // Per-step weight images (dvs_wimg.h): one workgroup per (job, 16-row slice).
 // ---------------------------------------------------------------------------------------------------------
 #include "dvs_wimg.h"
-__global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg) {
-    const int jb = blockIdx.x / 12, slice = blockIdx.x % 12;         // up to 192 rows = 12 slices of 16
-    if (jb >= jobs.count) return;
+__global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg, DvsLatImgArgs lat) {
+    const int nlat = 1024 * lat.NT / 64;                             // latent blocks come FIRST: their serial transposes overlap the rest
+    if ((int)blockIdx.x < nlat) {
+        // latent images (DvsLatImg): one workgroup per 64 consecutive frag positions k'; both orientations of every matrix are
+        // written as contiguous rows through an LDS tile (4-byte scatters at 4 KB stride cost this launch 7 us)
+        __shared__ float tile[64][65];
+        const int K = 1024 * lat.NT, kp0 = (int)blockIdx.x * 64;
+        const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const size_t ldw = (size_t)lat.N * 64;
+        auto col_of = [&](int kp, bool& valid) {
+            const int tile_i = kp >> 10, q = (kp & 1023) >> 2, kk = kp & 3, t = q >> 6, ln = q & 63;
+            const int tok = 16 * tile_i + (ln & 15), feat = 16 * t + 4 * (ln >> 4) + kk;
+            valid = tok < lat.N;
+            return (size_t)(valid ? tok : 0) * 64 + feat;
+        };
+        bool valid;
+        const size_t col = col_of(kp0 + l, valid);                 // this lane's position when lanes run over k'
+        float va[16];                                                // all loads first: a load -> store loop pays a round trip each
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = w + 4 * i;
+            va[i] = !valid ? 0.f : (o < 32 ? lat.fc1_w[o * ldw + col] : lat.fc2_w[(o - 32) * ldw + col]);
+        }
+        float v3[8];                                                 // lanes run over o (two k' per wave pass)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bool v2;
+            const size_t c2 = col_of(kp0 + 2 * (w + 4 * i) + (l >> 5), v2);
+            v3[i] = v2 ? lat.fc3_w[c2 * 32 + (l & 31)] : 0.f;
+        }
+        const float vb3 = valid ? lat.fc3_b[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = w + 4 * i;
+            tile[o][l] = va[i];
+            lat.img[DvsLatImg::A(lat.NT) + (size_t)o * K + kp0 + l] = va[i];
+        }
+        __syncthreads();
+        for (int j = w; j < 64; j += 4) lat.img[DvsLatImg::AT(lat.NT) + (size_t)(kp0 + j) * 64 + l] = tile[l][j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int jj = 2 * (w + 4 * i) + (l >> 5), o = l & 31;
+            tile[o][jj] = v3[i];
+            lat.img[DvsLatImg::W3(lat.NT) + (size_t)(kp0 + jj) * 32 + o] = v3[i];
+        }
+        __syncthreads();
+        for (int o = w; o < 32; o += 4) lat.img[DvsLatImg::W3T(lat.NT) + (size_t)o * K + kp0 + l] = tile[o][l];
+        if (w == 0) lat.img[DvsLatImg::B3(lat.NT) + kp0 + l] = vb3;
+        return;
+    }
+    const int jb = ((int)blockIdx.x - nlat) / 12, slice = ((int)blockIdx.x - nlat) % 12;         // up to 192 rows = 12 slices of 16
     const DvsImgJob J = jobs.job[jb];
     const bool transposed = J.flags & 1, rperm = J.flags & 2, cperm = J.flags & 4;
     const float* src = params + J.src;
@@ -100,6 +149,6 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
         }
     }
 }
-void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, dvs_stream_t st) {
-    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12), dim3(256), 0, st, jobs, params, wimg);
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat, dvs_stream_t st) {
+    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12 + 1024 * lat.NT / 64), dim3(256), 0, st, jobs, params, wimg, lat);
 }

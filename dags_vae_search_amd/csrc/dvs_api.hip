@@ -545,6 +545,14 @@ struct FwdChain {
         if (chain) next(DVS_FPH_FFN).u.f = f;
         else dvs_launch_ffn_fwd(f, g.tiles16, st);
     }
+    // the latent block as the last phase of the encoder chain (the workgroups of the chain own 16 DAGs each: one MFMA
+    // group); false: not chained, the caller launches k_latent_fwd
+    bool latent(const LatentArgs& l) {
+        static const bool off = getenv("DVS_LATENT_KERNELS") && atoi(getenv("DVS_LATENT_KERNELS")) != 0;   // A/B: own launches
+        if (!chain || off || stack.nphase == 0 || stack.nphase == DVS_FWD_STACK_PHASES) return false;
+        next(DVS_FPH_LATENT).u.l = l;
+        return true;
+    }
     void flush() {
         if (stack.nphase > 0) dvs_launch_fwd_stack(stack, tag, g.tiles8, st);
         stack.nphase = 0;
@@ -552,8 +560,10 @@ struct FwdChain {
 };
 
 // dec_embed: also write the decoder-side embedding (slot 7, dropout sites 2 / 3) from the same launch (one-tile path)
+// lat: the latent block's arguments; it runs as the last phase of the encoder chain when there is one, as k_latent_fwd otherwise
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
-                            const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st, bool dec_embed = false) {
+                            const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st, const LatentArgs& lat,
+                            bool dec_embed = false) {
     EmbedArgs e;
     memset(&e, 0, sizeof(e));
     e.dims = d;
@@ -615,7 +625,9 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         ln = DvsLN{ws + W.stats[sf], P + L.enc[i].n2.w, P + L.enc[i].n2.b};
         prev = sf;
     }
+    const bool fused = chain.latent(lat);
     chain.flush();
+    if (!fused) dvs_launch_latent_fwd(lat, st);
 }
 
 static LatentArgs latent_args(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const float* P, float* ws,
@@ -747,8 +759,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t 
 
     prepare_images(L, d.N, grid.wide, params, ws, W, st);
     const bool fused_dec_embed = d.drop.on && !grid.wide;
-    encoder_forward(d, L, W, rec, params, ws, grid, st, fused_dec_embed);
-    dvs_launch_latent_fwd(latent_args(d, L, W, params, ws, eps, true), st);
+    encoder_forward(d, L, W, rec, params, ws, grid, st, latent_args(d, L, W, params, ws, eps, true), fused_dec_embed);
 
     // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
     // only to redraw the dropout masks)
@@ -801,10 +812,9 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, size_t record
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
     prepare_images(L, d.N, is_wide(s), params, ws, W, st);
-    encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st);
     LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
     la.dims.training = 0;
-    dvs_launch_latent_fwd(la, st);
+    encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st, la);
     const size_t nb = (size_t)d.B * 32 * sizeof(float);
 #ifdef DVS_EMU
     memcpy(mu, ws + W.mu, nb);

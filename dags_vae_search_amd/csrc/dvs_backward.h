@@ -100,9 +100,11 @@ struct BwdPhase {
     } u;
 };
 struct BwdStackArgs {
-    int nphase, pad;
+    int nphase;
+    int has_latent;                          // run the latent block's backward (lat) ahead of phase 0 (encoder chain)
     BwdPhase ph[DVS_STACK_PHASES];
     DvsStagePlan plan[DVS_STACK_PHASES];     // filled by dvs_launch_bwd_stack (dvs_stage.h): what each phase keeps in LDS
+    LatentBwdArgs lat;
 };
 static_assert(sizeof(BwdStackArgs) <= 4096, "kernel argument block limit");
 void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 decoder, 1 encoder (profile names)

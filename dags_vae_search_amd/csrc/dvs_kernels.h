@@ -113,13 +113,15 @@ void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st);
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st);
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st);
 // One phase of a chained forward launch (k_fwd_stack, k_forward.hip): attention or FFN sublayer of the one-tile path.
-enum { DVS_FPH_ATTN = 0, DVS_FPH_FFN = 1 };
+// DVS_FPH_LATENT (encoder chain only, last phase): the latent block on the 16 DAGs the workgroup owns (dvs_latent.h).
+enum { DVS_FPH_ATTN = 0, DVS_FPH_FFN = 1, DVS_FPH_LATENT = 2 };
 #define DVS_FWD_STACK_PHASES 9
 struct FwdPhase {
     int kind, pad;
     union {
         AttnArgs a;
         FfnArgs f;
+        LatentArgs l;
     } u;
 };
 struct FwdStackArgs {

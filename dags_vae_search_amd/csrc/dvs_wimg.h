@@ -57,13 +57,16 @@ constexpr size_t DVS_WIMG_BF16 = DVS_WIMG_LOSS + DvsLossImg::SIZE;
 // kernels used to read the parameters in place: 64 scattered 16-byte (or 4-byte) pieces per wave load, every 128-byte line
 // fetched by four different waves of a workgroup — 250 MB of L2 reads per launch for 0.37 MB of weights.
 struct DvsLatImg {
-    // K = 1024 * NT.  A: [64 o][K] rows 0-31 fc1, 32-63 fc2;  AT: [K][64];  W3: [K][32] fc3 rows;  W3T: [32][K];  B3: [K] fc3 bias
+    // K = 1024 * NT.  A: [64 o][LD] rows 0-31 fc1, 32-63 fc2;  AT: [K][64];  W3: [K][32] fc3 rows;  W3T: [32][LD];  B3: [K] fc3 bias.
+    // LD = K + 64: with a power-of-two row pitch (4 KB at NT = 1) the 16 rows a wave load touches sit in ONE L2 channel and
+    // one L1 set — measured on the chained latent phase: 256 KB of weights per workgroup took 12 k cycles (21 B/clk).
+    static constexpr size_t LD(int NT) { return (size_t)1024 * NT + 64; }
     static constexpr size_t A(int) { return 0; }
-    static constexpr size_t AT(int NT) { return (size_t)64 * 1024 * NT; }
-    static constexpr size_t W3(int NT) { return (size_t)128 * 1024 * NT; }
-    static constexpr size_t W3T(int NT) { return (size_t)160 * 1024 * NT; }
-    static constexpr size_t B3(int NT) { return (size_t)192 * 1024 * NT; }
-    static constexpr size_t floats(int NT) { return (size_t)193 * 1024 * NT; }
+    static constexpr size_t AT(int NT) { return 64 * LD(NT); }
+    static constexpr size_t W3(int NT) { return AT(NT) + (size_t)64 * 1024 * NT; }
+    static constexpr size_t W3T(int NT) { return W3(NT) + (size_t)32 * 1024 * NT; }
+    static constexpr size_t B3(int NT) { return W3T(NT) + 32 * LD(NT); }
+    static constexpr size_t floats(int NT) { return B3(NT) + (size_t)1024 * NT; }
 };
 struct DvsLatImgArgs {
     const float *fc1_w, *fc2_w, *fc3_w, *fc3_b;      // parameter order: [32][N*64], [32][N*64], [N*64][32], [N*64]

@@ -1,5 +1,6 @@
 // Backward kernels of the transformer stack (phases: dvs_bwd_phases.h) and the slab reduce.
 #include "dvs_bwd_phases.h"
+#include "dvs_latent_bwd.h"
 
 __global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
@@ -64,6 +65,15 @@ __global__ __launch_bounds__(512) void k_bwd_stack(BwdStackArgs s) {
 #else
     const DvsPlanK plans = s.plan;
 #endif
+    if (TAG == 1 && s.has_latent) {
+        // latent block on the workgroup's DAGs, two 8-DAG runs (= two rounds of the phases' DAG loops) per MFMA group; its
+        // d enc_out tiles are read by other waves of this workgroup in phase 0: __syncthreads waits for the stores (vmcnt)
+        const int step = (int)gridDim.x * 8, B = s.lat.dims.B;
+        for (int base = dvs_bid() * 8; base < B; base += 2 * step) {
+            dvs_latent_bwd_group<8>(s.lat, (f4 (*)[2][64])smem, base, base + step);
+            __syncthreads();
+        }
+    }
     for (int i = 0; i < s.nphase; ++i) {
         const BwdPhase& ph = s.ph[i];
         const bool first = i == 0;                       // later phases: staged by the tail of the one before (dvs_stage.h)

@@ -1,6 +1,7 @@
 // Backward of the loss head, the embedding, and the latent block (fc1/fc2/fc3).
 #include "dvs_backward.h"
 #include "dvs_wimg.h"
+#include "dvs_latent_bwd.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Loss head backward (autograd of pace.py:1880-1972) fused with the last decoder LayerNorm's backward.
@@ -381,81 +382,10 @@ void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int
 // Latent block backward, part 1 (one wave per 16 DAGs): dz^T = fc3^T dmem^T; through the reparameterisation and
 // the KL term to (d mu, d logvar); then d enc_out^T = [fc1;fc2]^T [dmu;dlogvar]^T, stored frag order.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LATB_WAVES = 16;   // as k_latent_fwd: a latency-bound chunk walk spread over 16 waves per 16-DAG group
+constexpr int LATB_WAVES = 8;    // as the chained encoder backward runs it (k_bwd_stack): same summation order, bit for bit
 __global__ __launch_bounds__(64 * LATB_WAVES) void k_latent_bwd(LatentBwdArgs a) {
     __shared__ f4 part[LATB_WAVES][2][64];
-    const Lane L = dvs_lane();
-    const int B = a.dims.B, N = a.dims.N;
-    const float gkl = a.gcoef[1];
-    const int dag = blockIdx.x * 16 + L.r;
-    const bool dvalid = dag < B;
-    const int NT = a.dims.NT, mch = 64 * NT / LATB_WAVES;   // chunk m: tile m >> 6, chunk m & 63 of it (k_latent_fwd)
-    const size_t dstride = (size_t)NT * DVS_TILE;
-    const int m0 = mch * L.wave;
-    f4 dz[2] = {f4_zero(), f4_zero()};
-    const int K = 1024 * NT;
-    // d z^T = fc3^T d mem^T: A = row 16 t + r of the transposed fc3 image, contraction positions 16 m + 4 g .. + 3
-    const float* const w3t = a.limg + DvsLatImg::W3T(NT) + (size_t)L.r * K + 4 * L.g;
-#pragma unroll 8
-    for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi;
-        const f4 gb = dvalid ? *(const f4*)(a.gmem + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
-        f4 wa[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wa[t] = *(const f4*)(w3t + (size_t)16 * t * K + 16 * m);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) dz[t] = dvs_mfma(wa[t][kk], gb[kk], dz[t]);
-    }
-    part[L.wave][0][L.lane] = dz[0];
-    part[L.wave][1][L.lane] = dz[1];
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        dz[t] = part[0][t][L.lane];
-#pragma unroll
-        for (int w = 1; w < LATB_WAVES; ++w) dz[t] += part[w][t][L.lane];
-    }
-    // dz[t][reg] = d z[o = 16t + 4g + reg][dag r]
-    f4 dout[4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const size_t o4 = (size_t)(dvalid ? dag : 0) * 32 + 16 * t + 4 * L.g;
-        const f4 mu = *(const f4*)(a.mu + o4), lv = *(const f4*)(a.logvar + o4), ev = *(const f4*)(a.epsv + o4);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float dzz = dvalid ? dz[t][reg] : 0.f;
-            float dmu = dzz + gkl * mu[reg];
-            float dlv = gkl * 0.5f * (__expf(lv[reg]) - 1.0f);
-            if (a.dims.training) dlv += dzz * ev[reg] * 0.5f * __expf(0.5f * lv[reg]);
-            dout[t][reg] = dvalid ? dmu : 0.f;
-            dout[t + 2][reg] = dvalid ? dlv : 0.f;
-        }
-        if (dvalid && L.wave == 0) {
-            *(f4*)(a.gz + (size_t)dag * 64 + 16 * t + 4 * L.g) = dout[t];
-            *(f4*)(a.gz + (size_t)dag * 64 + 32 + 16 * t + 4 * L.g) = dout[t + 2];
-        }
-    }
-    // d enc_out^T[k'][dag] = sum_o Wfc[o][k'] dout^T[o][dag]: A = rows 16 m + r of the transposed [fc1; fc2] image (256 bytes each)
-    const float* const wat = a.limg + DvsLatImg::AT(NT) + (size_t)L.r * 64 + 4 * L.g;
-#pragma unroll 4
-    for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi, mm = m & 63;
-        const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;
-        f4 wa[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wa[t] = *(const f4*)(wat + (size_t)16 * m * 64 + 16 * t);
-        f4 o0 = f4_zero(), o1 = f4_zero();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            o0 = dvs_mfma(wa[0][kk], dout[0][kk], o0);
-            o1 = dvs_mfma(wa[1][kk], dout[1][kk], o1);
-            o0 = dvs_mfma(wa[2][kk], dout[2][kk], o0);
-            o1 = dvs_mfma(wa[3][kk], dout[3][kk], o1);
-        }
-        if (dvalid) *(f4*)(a.genc + (size_t)dag * dstride + 16 * m + 4 * L.g) = tokD < N ? o0 + o1 : f4_zero();
-    }
+    dvs_latent_bwd_group<LATB_WAVES>(a, part, (int)blockIdx.x * 16, (int)blockIdx.x * 16 + 8);
 }
 
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st) {

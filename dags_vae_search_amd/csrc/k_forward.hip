@@ -289,6 +289,9 @@ void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 #ifdef DVS_STAMPS
 DVS_STAMP_DECL(dvs_stamps_fwd);
+struct DvsLatTag { int phase; };
+__device__ const DvsLatTag dvs_lat_tag = {6};
+#define DVS_LAT_STAMP(id) DVS_STAMP(dvs_stamps_fwd, &dvs_lat_tag, id)
 // inner budget of the attention forward DAG loop: cycles summed over DAGs and phases, per (workgroup, wave, segment)
 __device__ unsigned long long dvs_stamps_attn[256 * 8 * 8];
 #define ASTAMP(k)                                                                                                   \
@@ -300,6 +303,7 @@ __device__ unsigned long long dvs_stamps_attn[256 * 8 * 8];
 #else
 #define ASTAMP(k) ((void)0)
 #endif
+#include "dvs_latent.h"
 struct AttnLds {
     dvs_bf16 *Win, *Wout;                     // bf16x6 image triples (dvs_bf16.h); in-projection rows / out-projection columns in slot order
     float *inb, *outb, *lg, *lb;
@@ -678,9 +682,20 @@ __global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
         const FwdPhase& ph = s.ph[i];
         const bool first = i == 0, more = i + 1 < s.nphase;
         const DvsPlanK mine = plans + i;
-        const DvsPlanK next = plans + (more ? i + 1 : i);
-        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem, mine, first, next, more);
-        else dvs_ffn_fwd_phase(ph.u.f, smem, mine, first, next, more);
+        if (TAG == 0 && ph.kind == DVS_FPH_LATENT) {
+            // the workgroup's DAGs, two 8-DAG runs (= two rounds of the phases' DAG loops) per group; the encoder output tiles
+            // were written by other waves of this workgroup: __syncthreads waits for every wave's stores (vmcnt) first
+            const int step = (int)gridDim.x * 8, B = ph.u.l.dims.B;
+            for (int base = dvs_bid() * 8; base < B; base += 2 * step) {
+                __syncthreads();
+                dvs_latent_fwd_group(ph.u.l, smem, base, base + step);
+            }
+            continue;
+        }
+        const bool more_img = more && s.ph[i + 1].kind != DVS_FPH_LATENT;      // the latent phase stages nothing
+        const DvsPlanK next = plans + (more_img ? i + 1 : i);
+        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem, mine, first, next, more_img);
+        else dvs_ffn_fwd_phase(ph.u.f, smem, mine, first, next, more_img);
         dvs_lds_barrier();               // publishes the next phase's staged images
     }
 }
@@ -689,7 +704,8 @@ void dvs_launch_fwd_stack(const FwdStackArgs& s_in, int tag, int grid, dvs_strea
     FwdStackArgs s = s_in;
     for (int i = 0; i < s.nphase; ++i) {
         if (s.ph[i].kind == DVS_FPH_ATTN) attn_plan(s.plan[i], s.ph[i].u.a, DVS_FAKE_LDS);
-        else ffn_plan(s.plan[i], s.ph[i].u.f, DVS_FAKE_LDS);
+        else if (s.ph[i].kind == DVS_FPH_FFN) ffn_plan(s.plan[i], s.ph[i].u.f, DVS_FAKE_LDS);
+        else dvs_plan_clear(s.plan[i]);
         s.plan[i].phase = i;
     }
 #ifdef DVS_STAMPS

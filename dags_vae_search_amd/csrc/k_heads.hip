@@ -1,6 +1,7 @@
 // Latent block (fc1/fc2 -> reparameterize -> KL -> fc3), loss head (node NLL + edge BCE) and loss finalisation.
 #include "dvs_kernels.h"
 #include "dvs_wimg.h"
+#include "dvs_latent.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Latent block forward (pace.py:1639-1641, 1649-1664, 1997, 2030).  One wave owns 16 DAGs:
@@ -9,102 +10,9 @@
 //                                                            token 4(m&3)+g, so weights are read in place)
 //   z^T = mu^T + eps * exp(logvar/2);  KL per DAG;  mem^T[N*64 x 16 dags] = fc3 * z^T + b3 (stored frag order)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dvs_normal(uint32_t key, uint32_t e) {
-    const uint32_t h1 = dvs_draw(key, 2 * e), h2 = dvs_draw(key, 2 * e + 1);
-    const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * __logf(u1)) * cosf(6.283185307179586f * u2);
-}
-
-// One workgroup (4 waves) per group of 16 DAGs: the contraction (fc1/fc2) and the output rows (fc3) are split over the
-// waves by 16-float chunk index m; the fc1/fc2 partial sums meet in LDS and are added in wave order.
-constexpr int LAT_WAVES = 8;     // waves per 16-DAG group: a serial, latency-bound chunk walk (measured: 4 waves 37 us, 8 waves 31 us, 16 waves 45 us)
 __global__ __launch_bounds__(64 * LAT_WAVES) void k_latent_fwd(LatentArgs a) {
     DVS_DYN_LDS(smem);
-    f4 (*part)[4][64] = (f4 (*)[4][64])smem;            // [LAT_WAVES][4][64]
-    const Lane L = dvs_lane();
-    const int B = a.dims.B, N = a.dims.N;
-    const int grp = blockIdx.x;
-    const int dag = grp * 16 + L.r;
-    const bool dvalid = dag < B;
-    f4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-    // chunk m of the DAG's NT frag-order tiles: tile m >> 6, 16-float chunk mm = m & 63 of that tile
-    const int NT = a.dims.NT, mch = 64 * NT / LAT_WAVES;
-    const size_t dstride = (size_t)NT * DVS_TILE;
-    const int m0 = mch * L.wave;
-    const int K = 1024 * NT;
-    // A operand: row 16 ot + r of the [fc1; fc2] image, contraction positions 16 m + 4 g .. + 3 (frag order, as the activations)
-    const float* const wrow = a.limg + DvsLatImg::A(NT) + (size_t)L.r * K + 4 * L.g;
-#pragma unroll 8
-    for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi;
-        const f4 xb = dvalid ? *(const f4*)(a.xenc + (size_t)dag * dstride + 16 * m + 4 * L.g) : f4_zero();
-        f4 wa[4];
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) wa[ot] = *(const f4*)(wrow + (size_t)16 * ot * K + 16 * m);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) acc[ot] = dvs_mfma(wa[ot][kk], xb[kk], acc[ot]);
-    }
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) part[L.wave][ot][L.lane] = acc[ot];
-    __syncthreads();
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) {
-        acc[ot] = *(const f4*)((ot < 2 ? a.fc1_b + 16 * ot : a.fc2_b + 16 * (ot - 2)) + 4 * L.g);
-#pragma unroll
-        for (int w = 0; w < LAT_WAVES; ++w) acc[ot] += part[w][ot][L.lane];
-    }
-    // acc[ot][reg] = out[o = 16(ot&1) + 4g + reg][dag r]; ot 0,1 = mu, ot 2,3 = logvar
-    float kl = 0.f;
-    f4 z[2];
-    const uint32_t key = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, 100u, a.dims.dag_offset + dag);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        f4 ev = f4_zero();
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float mu = acc[t][reg], lv = acc[t + 2][reg];
-            const float elv = __expf(lv);
-            kl += -0.5f * (1.0f + lv - mu * mu - elv);
-            float zz = mu;
-            if (a.dims.training) {
-                const int o = 16 * t + 4 * L.g + reg;
-                const float e = a.eps_in ? (dvalid ? a.eps_in[(size_t)dag * 32 + o] : 0.f)
-                                         : dvs_normal(key, (uint32_t)o) * a.dims.eps_scale;
-                ev[reg] = e;
-                zz = mu + e * __expf(0.5f * lv);
-            }
-            z[t][reg] = zz;
-        }
-        if (dvalid && L.wave == 0) {
-            const size_t o4 = (size_t)dag * 32 + 16 * t + 4 * L.g;
-            *(f4*)(a.mu + o4) = acc[t];
-            *(f4*)(a.logvar + o4) = acc[t + 2];
-            *(f4*)(a.z + o4) = z[t];
-            *(f4*)(a.epsv + o4) = ev;
-        }
-    }
-    kl = dvs_sum_g(kl);
-    if (L.wave == 0 && L.g == 0 && dvalid && a.dag_loss) a.dag_loss[(size_t)dag * 2 + 1] = kl;
-    if (!a.mem) return;
-    // mem^T chunk m (rows k' = 16 m ..): A = fc3 image rows (one 128-byte row per lane r, 16 bytes per (t, g)), bias in place
-    const float* const w3 = a.limg + DvsLatImg::W3(NT) + (size_t)L.r * 32 + 4 * L.g;
-    const float* const b3 = a.limg + DvsLatImg::B3(NT) + 4 * L.g;
-#pragma unroll 8
-    for (int mi = 0; mi < mch; ++mi) {
-        const int m = m0 + mi, mm = m & 63;
-        const int tokD = 16 * (m >> 6) + 4 * (mm & 3) + L.g;            // token of this lane's 4 result rows
-        f4 o = *(const f4*)(b3 + 16 * m);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f4 wa = *(const f4*)(w3 + (size_t)16 * m * 32 + 16 * t);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) o = dvs_mfma(wa[kk], z[t][kk], o);
-        }
-        if (dvalid) *(f4*)(a.mem + (size_t)dag * dstride + 16 * m + 4 * L.g) = tokD < N ? o : f4_zero();
-    }
+    dvs_latent_fwd_group(a, smem, (int)blockIdx.x * 16, (int)blockIdx.x * 16 + 8);
 }
 
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st) {

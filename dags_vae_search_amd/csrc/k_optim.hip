@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
         for (int i = 0; i < 16; ++i) {
             const int o = w + 4 * i;
             tile[o][l] = va[i];
-            lat.img[DvsLatImg::A(lat.NT) + (size_t)o * K + kp0 + l] = va[i];
+            lat.img[DvsLatImg::A(lat.NT) + (size_t)o * DvsLatImg::LD(lat.NT) + kp0 + l] = va[i];
         }
         __syncthreads();
         for (int j = w; j < 64; j += 4) lat.img[DvsLatImg::AT(lat.NT) + (size_t)(kp0 + j) * 64 + l] = tile[l][j];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
             lat.img[DvsLatImg::W3(lat.NT) + (size_t)(kp0 + jj) * 32 + o] = v3[i];
         }
         __syncthreads();
-        for (int o = w; o < 32; o += 4) lat.img[DvsLatImg::W3T(lat.NT) + (size_t)o * K + kp0 + l] = tile[o][l];
+        for (int o = w; o < 32; o += 4) lat.img[DvsLatImg::W3T(lat.NT) + (size_t)o * DvsLatImg::LD(lat.NT) + kp0 + l] = tile[o][l];
         if (w == 0) lat.img[DvsLatImg::B3(lat.NT) + kp0 + l] = vb3;
         return;
     }

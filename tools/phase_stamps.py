@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
     from dags_vae_search_amd import _lib as dl
-    dl.LIB_NAME = "libdvs_hip_stamps.so"
+    dl.LIB_NAME = os.environ.get("DVS_STAMPS_LIB", "libdvs_hip_stamps.so")      # variant builds of the diagnostic library
     from dags_vae_search_amd import PaceVaeV3, optim as dopt, prepare_features
     from dags_vae_search_amd.synthetic import synthetic_dags
     from dags_vae_search_amd.train import train_batch
@@ -54,6 +54,12 @@ def main():
         t = buf.reshape(WGS, WAVES, PH, IDS).astype(np.int64)
         print(f"== {name}: cycles, mean over {WGS} workgroups (older group = wave 0, younger = wave 4) ==")
         print("phase   stage  loop_old loop_yng   issue   waitA_old waitA_yng     epi  commit   total")
+        if name == "forward" and t[:, 0, 6, 3].any():        # latent block chained behind the encoder (ids 0..3, dvs_latent.h)
+            lt = t[:, :, 6, :4]
+            print("latent phase (wave 0 / wave 7): contraction %d / %d, partial sums + barrier %d / %d, epilogue %d / %d" % (
+                np.mean(lt[:, 0, 1] - lt[:, 0, 0]), np.mean(lt[:, 7, 1] - lt[:, 7, 0]), np.mean(lt[:, 0, 2] - lt[:, 0, 1]),
+                np.mean(lt[:, 7, 2] - lt[:, 7, 1]), np.mean(lt[:, 0, 3] - lt[:, 0, 2]), np.mean(lt[:, 7, 3] - lt[:, 7, 2])))
+            t[:, :, 6, :] = 0
         for ph in range(PH):
             if not t[:, 0, ph, 1].any():
                 continue

@@ -432,7 +432,7 @@ static inline int blk_dec_cross(int layer) { return 4 + 2 * layer; }
 static inline int blk_enc_ffn(int layer) { return layer; }
 static inline int blk_dec_ffn(int layer) { return 3 + layer; }
 
-static void prepare_images(const DvsLayout& L, int N, bool wide, const float* params, float* ws, const DvsWorkspace& W,
+static void prepare_images(const DvsLayout& L, int N, int C, bool wide, const float* params, float* ws, const DvsWorkspace& W,
                            dvs_stream_t st) {
     DvsImgJobs J;
     J.count = 0;
@@ -482,7 +482,22 @@ static void prepare_images(const DvsLayout& L, int N, bool wide, const float* pa
     lat.img = ws + W.limg;
     lat.N = N;
     lat.NT = (N + 15) / 16;
-    dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), lat, st);
+    DvsLossHeadArgs head;
+    memset(&head, 0, sizeof(head));
+    if (!wide) {
+        head.node0_w = params + L.node0_w;
+        head.node0_b = params + L.node0_b;
+        head.node2_w = params + L.node2_w;
+        head.node2_b = params + L.node2_b;
+        head.edge0_b = params + L.edge0_b;
+        head.edge2_w = params + L.edge2_w;
+        head.edge2_b = params + L.edge2_b;
+        head.ln_g = params + L.dec[DVS_LAYERS - 1].n3.w;
+        head.ln_b = params + L.dec[DVS_LAYERS - 1].n3.b;
+        head.dst = (float*)((dvs_bf16*)(ws + W.wimg) + DVS_WIMG_LOSS + DvsLossImg::Head);
+        head.C = C;
+    }
+    dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), lat, head, st);
 }
 static inline const void* wimg_attn(const float* ws, const DvsWorkspace& W, int block) {
     return (const dvs_bf16*)(ws + W.wimg) + img_attn(block);
@@ -757,7 +772,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t 
     dvs_stream_t st = (dvs_stream_t)stream;
     const FwdGrids grid = fwd_grids(d, is_wide(s));
 
-    prepare_images(L, d.N, grid.wide, params, ws, W, st);
+    prepare_images(L, d.N, d.C, grid.wide, params, ws, W, st);
     const bool fused_dec_embed = d.drop.on && !grid.wide;
     encoder_forward(d, L, W, rec, params, ws, grid, st, latent_args(d, L, W, params, ws, eps, true), fused_dec_embed);
 
@@ -811,7 +826,7 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, size_t record
     const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
-    prepare_images(L, d.N, is_wide(s), params, ws, W, st);
+    prepare_images(L, d.N, d.C, is_wide(s), params, ws, W, st);
     LatentArgs la = latent_args(d, L, W, params, ws, nullptr, false);
     la.dims.training = 0;
     encoder_forward(d, L, W, (const DvsRecord*)records, params, ws, fwd_grids(d, is_wide(s)), st, la);
@@ -848,7 +863,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, int64_t n_par
     const FwdGrids grid = fwd_grids(d, wide);
     const DvsRecord* rec = (const DvsRecord*)records;
 
-    prepare_images(L, d.N, wide, params, ws, W, st);
+    prepare_images(L, d.N, d.C, wide, params, ws, W, st);
     dvs_launch_decode_memory(d, z, params + L.fc3_w, params + L.fc3_b, ws + W.mem, st);
     DecodeArgs a;
     memset(&a, 0, sizeof(a));

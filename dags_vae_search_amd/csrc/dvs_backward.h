@@ -118,7 +118,6 @@ void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st);
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st);
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
                           float eps, int64_t step, float max_norm, float* scratch, const float* guard, dvs_stream_t st);
-size_t dvs_loss_lds_floats(int nwaves, int tiles_per_wave);
 
 // ---- slab reduction helpers ---------------------------------------------------------------------------------------
 // After its DAG loop a workgroup adds its waves' register accumulators and writes ONE partial per parameter to its

@@ -44,7 +44,19 @@ struct DvsLossImg {
     static constexpr size_t Wb = 3 * DVS_IMG64;
     static constexpr size_t WaT = 6 * DVS_IMG64;
     static constexpr size_t WbT = 8 * DVS_IMG64;
-    static constexpr size_t SIZE = 10 * DVS_IMG64;
+    // fp32 "head block" behind the images, exactly as k_loss_fwd / k_loss_bwd keep it in LDS (dvs_loss.h), so that the whole loss
+    // block is ONE verbatim copy (dvs_stage.h) instead of ten staging loops with a memory round trip each:
+    //   Wn1 [32][DVS_LD] add_node.0.weight | Wn2 [16][36] add_node.2.weight (rows >= C zero) | bn1 [32] | bn2 [16] | be1 [64]
+    //   add_edge.0.bias | w2 [64] add_edge.2.weight | b2 [16] (first: add_edge.2.bias) | lg [64], lb [64] last decoder LayerNorm
+    static constexpr size_t Head = 10 * DVS_IMG64;                 // bf16 units, like the rest
+    static constexpr int HEAD_FLOATS = 32 * 68 + 16 * 36 + 32 + 16 + 64 + 64 + 16 + 64 + 64;      // 3072 = 12 wave chunks
+    static constexpr size_t SIZE = Head + 2 * (size_t)HEAD_FLOATS;
+};
+static_assert(DvsLossImg::HEAD_FLOATS % 256 == 0 && DVS_LD == 68, "whole 1 KB chunks (dvs_stage.h)");
+struct DvsLossHeadArgs {
+    const float *node0_w, *node0_b, *node2_w, *node2_b, *edge0_b, *edge2_w, *edge2_b, *ln_g, *ln_b;
+    float* dst;                  // null: no head block (wide path)
+    int C;
 };
 // blocks of one step: encoder layer i -> attention block 3i ... see dvs_api.hip (img_enc_attn etc.); the loss block is last
 constexpr int DVS_N_ATTN_BLOCKS = 9, DVS_N_FFN_BLOCKS = 6;
@@ -85,7 +97,8 @@ struct DvsImgJobs {
     DvsImgJob job[DVS_MAX_IMG_JOBS];
     int count;
 };
-void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat, dvs_stream_t st);
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat,
+                               const DvsLossHeadArgs& head, dvs_stream_t st);
 
 // LDS <- global image copy, 16 bytes per lane (n = bf16 count, a multiple of 8; both 16-byte aligned).  Loads are issued
 // in batches of 8 per thread before the first store: a load -> store loop pays one full L2 round trip per iteration

@@ -2,52 +2,16 @@
 #include "dvs_backward.h"
 #include "dvs_wimg.h"
 #include "dvs_latent_bwd.h"
+#include "dvs_loss.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Loss head backward (autograd of pace.py:1880-1972) fused with the last decoder LayerNorm's backward.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LOSS_LDN2 = 36;
-struct LossBLds {
-    dvs_bf16 *Wa, *Wb;           // bf16x6 triples (recompute of U, V exactly as k_loss_fwd)
-    dvs_bf16 *WaT, *WbT;         // bf16x3 pairs of the transposes (d h)
-    float *Wn1, *Wn2, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *scr;
-};
-__device__ __forceinline__ LossBLds lossb_lds(char* smem) {
-    LossBLds l;
-    l.Wa = (dvs_bf16*)smem;
-    l.Wb = l.Wa + 3 * DVS_IMG64;
-    l.WaT = l.Wb + 3 * DVS_IMG64;
-    l.WbT = l.WaT + 2 * DVS_IMG64;
-    l.Wn1 = (float*)(l.WbT + 2 * DVS_IMG64);
-    l.Wn2 = l.Wn1 + 32 * DVS_LD;
-    l.bn1 = l.Wn2 + 16 * LOSS_LDN2;
-    l.bn2 = l.bn1 + 32;
-    l.be1 = l.bn2 + 16;
-    l.w2 = l.be1 + 64;
-    l.b2 = l.w2 + 64;
-    l.lg = l.b2 + 16;
-    l.lb = l.lg + 64;
-    l.scr = l.lb + 64;
-    return l;
-}
-
-__global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
+__global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    const LossBLds l = lossb_lds(smem);
+    const LossLds l = loss_lds(smem);
     const int N = a.dims.N, C = a.dims.C;
-    dvs_stage_matrix(l.Wn1, DVS_LD, a.node0_w, 64, 32, 64);
-    for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
-        const int c = i >> 5, k = i & 31;
-        l.Wn2[c * LOSS_LDN2 + k] = c < C ? a.node2_w[c * 32 + k] : 0.f;
-    }
-    dvs_copy_image(l.Wa, (const dvs_bf16*)a.wimg + DvsLossImg::Wa, (int)DvsLossImg::SIZE);     // the whole loss block, in image order
-    dvs_stage_vector(l.bn1, a.node0_b, 32);
-    for (int i = threadIdx.x; i < 16; i += blockDim.x) l.bn2[i] = i < C ? a.node2_b[i] : 0.f;
-    dvs_stage_vector(l.be1, a.edge0_b, 64);
-    dvs_stage_vector(l.w2, a.edge2_w, 64);
-    if (threadIdx.x == 0) l.b2[0] = a.edge2_b[0];
-    dvs_stage_vector(l.lg, a.ln.g, 64);
-    dvs_stage_vector(l.lb, a.ln.b, 64);
+    dvs_stage_now<(LOSS_CHUNKS + 3) / 4>(&plan, smem);        // the whole loss block (dvs_wimg.h) in one batch of loads
     __syncthreads();
     const Lane L = dvs_lane();
     float* scrV = l.scr + L.wave * 3 * DVS_SCR;
@@ -251,11 +215,13 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a) {
 }
 
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = (dvs_loss_lds_floats(4, 3) + 4 * DVS_IMG64 / 2) * 4;        // + the two transposed x3 pairs
+    size_t lds = loss_lds_bytes(4, 3);
+    DvsStagePlan plan;
+    loss_plan(plan, a);
     const size_t red = (2 * DVS_RED_MAT) * 4;
     if (lds < red) lds = red;
     DVS_SET_LDS(k_loss_bwd, lds);
-    DVS_LAUNCH(k_loss_bwd, dim3(grid), dim3(256), lds, st, a);
+    DVS_LAUNCH(k_loss_bwd, dim3(grid), dim3(256), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -73,8 +73,44 @@ void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, floa
 // Per-step weight images (dvs_wimg.h): one workgroup per (job, 16-row slice).
 // ---------------------------------------------------------------------------------------------------------
 #include "dvs_wimg.h"
-__global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg, DvsLatImgArgs lat) {
+__device__ __forceinline__ float dvs_loss_head_value(const DvsLossHeadArgs& h, int i) {      // element i of the head block
+    if (i < 32 * 68) {
+        const int r = i / 68, c = i % 68;
+        return c < 64 ? h.node0_w[r * 64 + c] : 0.f;
+    }
+    i -= 32 * 68;
+    if (i < 16 * 36) {
+        const int c = i / 36, k = i % 36;
+        return (c < h.C && k < 32) ? h.node2_w[c * 32 + k] : 0.f;
+    }
+    i -= 16 * 36;
+    if (i < 32) return h.node0_b[i];
+    i -= 32;
+    if (i < 16) return i < h.C ? h.node2_b[i] : 0.f;
+    i -= 16;
+    if (i < 64) return h.edge0_b[i];
+    i -= 64;
+    if (i < 64) return h.edge2_w[i];
+    i -= 64;
+    if (i < 16) return i == 0 ? h.edge2_b[0] : 0.f;
+    i -= 16;
+    if (i < 64) return h.ln_g[i];
+    return h.ln_b[i - 64];
+}
+__global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg, DvsLatImgArgs lat,
+                                                        DvsLossHeadArgs head) {
     const int nlat = 1024 * lat.NT / 64;                             // latent blocks come FIRST: their serial transposes overlap the rest
+    const int first_job = nlat + (head.dst ? 1 : 0);                 // then one block for the loss head block (dvs_wimg.h), then the jobs
+    if (head.dst) {
+        if ((int)blockIdx.x == nlat) {
+            float v[DvsLossImg::HEAD_FLOATS / 256];
+#pragma unroll
+            for (int u = 0; u < DvsLossImg::HEAD_FLOATS / 256; ++u) v[u] = dvs_loss_head_value(head, u * 256 + (int)threadIdx.x);
+#pragma unroll
+            for (int u = 0; u < DvsLossImg::HEAD_FLOATS / 256; ++u) head.dst[u * 256 + threadIdx.x] = v[u];
+            return;
+        }
+    }
     if ((int)blockIdx.x < nlat) {
         // latent images (DvsLatImg): one workgroup per 64 consecutive frag positions k'; both orientations of every matrix are
         // written as contiguous rows through an LDS tile (4-byte scatters at 4 KB stride cost this launch 7 us)
@@ -124,7 +160,7 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
         if (w == 0) lat.img[DvsLatImg::B3(lat.NT) + kp0 + l] = vb3;
         return;
     }
-    const int jb = ((int)blockIdx.x - nlat) / 12, slice = ((int)blockIdx.x - nlat) % 12;         // up to 192 rows = 12 slices of 16
+    const int jb = ((int)blockIdx.x - first_job) / 12, slice = ((int)blockIdx.x - first_job) % 12;         // up to 192 rows = 12 slices of 16
     const DvsImgJob J = jobs.job[jb];
     const bool transposed = J.flags & 1, rperm = J.flags & 2, cperm = J.flags & 4;
     const float* src = params + J.src;
@@ -149,6 +185,8 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
         }
     }
 }
-void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat, dvs_stream_t st) {
-    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12 + 1024 * lat.NT / 64), dim3(256), 0, st, jobs, params, wimg, lat);
+void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat,
+                               const DvsLossHeadArgs& head, dvs_stream_t st) {
+    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12 + 1024 * lat.NT / 64 + (head.dst ? 1 : 0)), dim3(256), 0, st, jobs, params,
+               wimg, lat, head);
 }

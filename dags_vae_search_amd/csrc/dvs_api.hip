@@ -496,6 +496,12 @@ static void prepare_images(const DvsLayout& L, int N, int C, bool wide, const fl
         head.ln_b = params + L.dec[DVS_LAYERS - 1].n3.b;
         head.dst = (float*)((dvs_bf16*)(ws + W.wimg) + DVS_WIMG_LOSS + DvsLossImg::Head);
         head.C = C;
+        head.W1 = params + L.W1;
+        head.W2 = params + L.W2;
+        head.lab_w = params + L.lab_w;
+        head.lab_b = params + L.lab_b;
+        head.dst_emb = (float*)((dvs_bf16*)(ws + W.wimg) + DVS_WIMG_EMB);
+        head.N = N;
     }
     dvs_launch_prepare_images(J, params, (dvs_bf16*)(ws + W.wimg), lat, head, st);
 }
@@ -587,6 +593,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
     e.W2 = P + L.W2;
     e.lab_w = P + L.lab_w;
     e.lab_b = P + L.lab_b;
+    e.embimg = (const float*)((const dvs_bf16*)(ws + W.wimg) + DVS_WIMG_EMB);
     e.out = ws + W.act[0];
     e.site = 0;
     if (dec_embed) {
@@ -788,6 +795,7 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t 
         e.W2 = params + L.W2;
         e.lab_w = params + L.lab_w;
         e.lab_b = params + L.lab_b;
+        e.embimg = (const float*)((const dvs_bf16*)(ws + W.wimg) + DVS_WIMG_EMB);
         e.out = ws + W.act[7];
         e.site = 2;
         launch_embed_fwd(e, grid, st);
@@ -893,6 +901,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, int64_t n_par
         e.W2 = params + L.W2;
         e.lab_w = params + L.lab_w;
         e.lab_b = params + L.lab_b;
+        e.embimg = (const float*)((const dvs_bf16*)(ws + W.wimg) + DVS_WIMG_EMB);
         e.out = ws + W.act[7];
         e.site = 2;
         launch_embed_fwd(e, grid, st);

@@ -30,6 +30,7 @@ struct EmbedArgs {
     DvsDims dims;
     const DvsRecord* rec;
     const float *W1, *W2, *lab_w, *lab_b;
+    const float* embimg;         // embedding block of this step (dvs_wimg.h: DvsEmbImg); one-tile kernels stage it verbatim
     float* out;                  // [B][1024] frag order
     int site;                    // dropout site of the first dropout (second = site + 1)
     float* out2;                 // optional second embedding of the same graphs under dropout sites (site2, site2 + 1):

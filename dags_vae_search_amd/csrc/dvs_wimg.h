@@ -53,15 +53,24 @@ struct DvsLossImg {
     static constexpr size_t SIZE = Head + 2 * (size_t)HEAD_FLOATS;
 };
 static_assert(DvsLossImg::HEAD_FLOATS % 256 == 0 && DVS_LD == 68, "whole 1 KB chunks (dvs_stage.h)");
+// Embedding block (k_embed_fwd / k_embed_bwd, one-tile path), fp32, in the kernels' LDS layout:
+//   W1 [32][DVS_LD] (rows >= 2 N zero) | W2 [64][36] | lab_w [32][16] (classes >= C zero) | lab_b [32] | pad to whole 1 KB chunks
+struct DvsEmbImg {
+    static constexpr int FLOATS = 5120;                            // 2176 + 2304 + 512 + 32 = 5024, padded: 20 wave chunks
+};
 struct DvsLossHeadArgs {
     const float *node0_w, *node0_b, *node2_w, *node2_b, *edge0_b, *edge2_w, *edge2_b, *ln_g, *ln_b;
     float* dst;                  // null: no head block (wide path)
     int C;
+    const float *W1, *W2, *lab_w, *lab_b;                          // embedding block (dst_emb, same launch)
+    float* dst_emb;
+    int N;
 };
 // blocks of one step: encoder layer i -> attention block 3i ... see dvs_api.hip (img_enc_attn etc.); the loss block is last
 constexpr int DVS_N_ATTN_BLOCKS = 9, DVS_N_FFN_BLOCKS = 6;
 constexpr size_t DVS_WIMG_LOSS = DVS_N_ATTN_BLOCKS * DvsAttnImg::SIZE + DVS_N_FFN_BLOCKS * DvsFfnImg::SIZE;
-constexpr size_t DVS_WIMG_BF16 = DVS_WIMG_LOSS + DvsLossImg::SIZE;
+constexpr size_t DVS_WIMG_EMB = DVS_WIMG_LOSS + DvsLossImg::SIZE;      // embedding block (fp32, DvsEmbImg)
+constexpr size_t DVS_WIMG_BF16 = DVS_WIMG_EMB + 2 * (size_t)DvsEmbImg::FLOATS;
 
 // Latent block (fc1 / fc2 / fc3; k_latent_fwd, k_latent_bwd): fp32 images whose contraction / row index is the FRAG-ORDER
 // position k' of the DAG's activation tiles (k' -> token 16 tile + r', feature 16 t + 4 g' + kk; zero where the token is beyond

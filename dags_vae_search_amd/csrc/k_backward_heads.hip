@@ -230,7 +230,7 @@ void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
 // Handles up to two gradient sources per DAG (encoder-side and decoder-side embeddings: same weights, different
 // dropout sites).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gout2, int site2) {
+__global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gout2, int site2, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
     float* W1 = (float*)smem;                        // [32][LD], rows >= 2N zero
@@ -238,15 +238,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
     float* labw = W2 + 64 * EMB_LDW2;                // [32][16]
     float* labb = labw + 32 * 16;                    // [32]
     float* scr0 = labb + 32;                         // nwaves tiles
-    for (int i = threadIdx.x; i < 2 * DVS_MAXTOK * DVS_LD; i += blockDim.x) W1[i] = 0.f;
-    __syncthreads();
-    dvs_stage_matrix(W1, DVS_LD, a.W1, 64, 2 * N, 64);
-    dvs_stage_matrix(W2, EMB_LDW2, a.W2, 32, 64, 32);
-    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
-        const int f = i >> 4, c = i & 15;
-        labw[i] = c < C ? a.lab_w[f * C + c] : 0.f;
-    }
-    dvs_stage_vector(labb, a.lab_b, 32);
+    dvs_stage_now<5>(&plan, smem);           // the embedding block (dvs_wimg.h: DvsEmbImg) in one batch: 20 wave chunks on 4 waves
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -340,8 +332,12 @@ void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int
     size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
     const size_t red = (4 * (1024 + 1024 + 512 + 2048) + 4 * 32 + 4 * DVS_SCR) * 4;
     if (lds < red) lds = red;
+    DvsStagePlan plan;
+    dvs_plan_clear(plan);
+    dvs_plan_seg(plan, DVS_FAKE_LDS, DVS_FAKE_LDS, a.embimg, 2 * DvsEmbImg::FLOATS);
+    dvs_plan_seal(plan);
     DVS_SET_LDS(k_embed_bwd, lds);
-    DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2);
+    DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -208,21 +208,16 @@ __device__ __forceinline__ EmbLds emb_lds(char* smem) {
     l.scr = l.labb + 32;
     return l;
 }
-static size_t emb_lds_floats(int nwaves) { return 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + (size_t)nwaves * 16; }
+static size_t emb_lds_floats(int nwaves) {          // at least the padded block (DvsEmbImg::FLOATS): the copy is verbatim
+    const size_t n = 2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + (size_t)nwaves * 16;
+    return n > (size_t)DvsEmbImg::FLOATS ? n : (size_t)DvsEmbImg::FLOATS;
+}
 
-__global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a) {
+__global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
     const EmbLds l = emb_lds(smem);
-    for (int i = threadIdx.x; i < 2 * DVS_MAXTOK * DVS_LD; i += blockDim.x) l.W1[i] = 0.f;
-    __syncthreads();
-    dvs_stage_matrix(l.W1, DVS_LD, a.W1, 64, 2 * N, 64);
-    dvs_stage_matrix(l.W2, EMB_LDW2, a.W2, 32, 64, 32);
-    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
-        const int f = i >> 4, c = i & 15;
-        l.labw[i] = c < C ? a.lab_w[f * C + c] : 0.f;
-    }
-    dvs_stage_vector(l.labb, a.lab_b, 32);
+    dvs_stage_now<2>(&plan, smem);           // the embedding block (dvs_wimg.h) in one batch: 20 wave chunks on 16 waves
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -277,8 +272,12 @@ __global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a) {
 
 void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
     const size_t lds = emb_lds_floats(16) * 4;
+    DvsStagePlan plan;
+    dvs_plan_clear(plan);
+    dvs_plan_seg(plan, DVS_FAKE_LDS, DVS_FAKE_LDS, a.embimg, 2 * DvsEmbImg::FLOATS);
+    dvs_plan_seal(plan);
     DVS_SET_LDS(k_embed_fwd, lds);
-    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(1024), lds, st, a);
+    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(1024), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -97,11 +97,37 @@ __device__ __forceinline__ float dvs_loss_head_value(const DvsLossHeadArgs& h, i
     if (i < 64) return h.ln_g[i];
     return h.ln_b[i - 64];
 }
+__device__ __forceinline__ float dvs_emb_block_value(const DvsLossHeadArgs& h, int i) {      // element i of the embedding block
+    if (i < 32 * 68) {
+        const int r = i / 68, c = i % 68;
+        return (r < 2 * h.N && c < 64) ? h.W1[r * 64 + c] : 0.f;
+    }
+    i -= 32 * 68;
+    if (i < 64 * 36) {
+        const int f = i / 36, k = i % 36;
+        return k < 32 ? h.W2[f * 32 + k] : 0.f;
+    }
+    i -= 64 * 36;
+    if (i < 512) {
+        const int f = i >> 4, c = i & 15;
+        return c < h.C ? h.lab_w[f * h.C + c] : 0.f;
+    }
+    i -= 512;
+    return i < 32 ? h.lab_b[i] : 0.f;
+}
 __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const float* params, dvs_bf16* wimg, DvsLatImgArgs lat,
                                                         DvsLossHeadArgs head) {
     const int nlat = 1024 * lat.NT / 64;                             // latent blocks come FIRST: their serial transposes overlap the rest
-    const int first_job = nlat + (head.dst ? 1 : 0);                 // then one block for the loss head block (dvs_wimg.h), then the jobs
+    const int first_job = nlat + (head.dst ? 2 : 0);                 // then the loss head block and the embedding block, then the jobs
     if (head.dst) {
+        if ((int)blockIdx.x == nlat + 1) {
+            float v[DvsEmbImg::FLOATS / 256];
+#pragma unroll
+            for (int u = 0; u < DvsEmbImg::FLOATS / 256; ++u) v[u] = dvs_emb_block_value(head, u * 256 + (int)threadIdx.x);
+#pragma unroll
+            for (int u = 0; u < DvsEmbImg::FLOATS / 256; ++u) head.dst_emb[u * 256 + threadIdx.x] = v[u];
+            return;
+        }
         if ((int)blockIdx.x == nlat) {
             float v[DvsLossImg::HEAD_FLOATS / 256];
 #pragma unroll
@@ -187,6 +213,6 @@ __global__ __launch_bounds__(256) void k_prepare_images(DvsImgJobs jobs, const f
 }
 void dvs_launch_prepare_images(const DvsImgJobs& jobs, const float* params, dvs_bf16* wimg, const DvsLatImgArgs& lat,
                                const DvsLossHeadArgs& head, dvs_stream_t st) {
-    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12 + 1024 * lat.NT / 64 + (head.dst ? 1 : 0)), dim3(256), 0, st, jobs, params,
+    DVS_LAUNCH(k_prepare_images, dim3(jobs.count * 12 + 1024 * lat.NT / 64 + (head.dst ? 2 : 0)), dim3(256), 0, st, jobs, params,
                wimg, lat, head);
 }

@@ -7,7 +7,31 @@
 // ---------------------------------------------------------------------------------------------------------
 // Loss head backward (autograd of pace.py:1880-1972) fused with the last decoder LayerNorm's backward.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef DVS_STAMPS
+// inner budget of k_loss_bwd (tools/loss_stamps.py): cycles summed over the wave's DAGs, per (workgroup, wave, segment)
+__device__ unsigned long long dvs_stamps_lossb[256 * 4 * 12];
+#define LBSTAMP(k)                                                                                                         \
+    do {                                                                                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) dvs_stamps_lossb[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (k)] += now_ - lst_; \
+        lst_ = now_;                                                                                                       \
+    } while (0)
+extern "C" int dvs_debug_read_stamps_lossb(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_lossb)) bytes = sizeof(dvs_stamps_lossb);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_lossb), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_lossb)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_lossb)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#else
+#define LBSTAMP(k) ((void)0)
+#endif
 __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan) {
+#ifdef DVS_STAMPS
+    unsigned long long lst_ = __builtin_amdgcn_s_memtime();
+#endif
     DVS_DYN_LDS(smem);
     const LossLds l = loss_lds(smem);
     const int N = a.dims.N, C = a.dims.C;
@@ -35,6 +59,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         for (int j = 0; j < 4; ++j) dWn1[i][j] = f4_zero();
     }
     dbn2[0] = f4_zero();
+    LBSTAMP(0);                  // staging + barrier + accumulator init
     for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
         f4 h[4], xhat[4];
         float rstd;
@@ -42,6 +67,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         const DvsRecord* rec = a.rec + dag;
         f4 hN[4];
         dvs_t2n<4>(hN, h, scrV, L);
+        LBSTAMP(1);              // tile load + LayerNorm + transpose
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
         // ---- node head ----------------------------------------------------------------------------------
         {
@@ -93,6 +119,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
             dvs_outer_acc<2, 4>(dWn1, dt1N, hN);
             dvs_mat_Tt<4, 2>(dh, dt1, l.Wn1, DVS_LD, 0, L);
         }
+        LBSTAMP(2);              // node head forward + backward
         // ---- edge head ----------------------------------------------------------------------------------
         f4 U[4], V[4], w2v[4], dU[4], dV[4];
 #pragma unroll
@@ -114,6 +141,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         }
         dvs_wave_sync();
         const unsigned par = rec->parents[(L.r + 1) & 15];
+        LBSTAMP(3);              // U, V recompute + park
         // pass 1: lane r = i walks j; accumulates dU, dw2, db2; publishes d logit(i, j)
 #pragma unroll 2
         for (int j = 0; j < N - 2; ++j) {
@@ -146,6 +174,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
             }
         }
         dvs_wave_sync();
+        LBSTAMP(4);              // pass 1
         // pass 2: lane r = j walks i; accumulates dV
 #pragma unroll 2
         for (int i = 1; i <= N - 2; ++i) {
@@ -158,6 +187,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
             }
         }
         dvs_wave_sync();
+        LBSTAMP(5);              // pass 2
 #pragma unroll
         for (int t = 0; t < 4; ++t) dbe1[t] += dV[t];
         f4 dUN[4], dVN[4];
@@ -165,12 +195,15 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         dvs_t2n<4>(dVN, dV, scrV, L);
         dvs_outer_acc<4, 4>(dWa, dUN, hN);
         dvs_outer_acc<4, 4>(dWb, dVN, hN);
+        LBSTAMP(6);              // transposes + dWa, dWb outer products
         dvs_matb_T<4>(dh, dvs_split_T(dU), l.WaT, l.WaT + DVS_IMG64, 0, L);       // d h += Wa^T dU + Wb^T dV (bf16x3: smooth)
         dvs_matb_T<4>(dh, dvs_split_T(dV), l.WbT, l.WbT + DVS_IMG64, 0, L);
         dvs_ln_bwd(dh, xhat, rstd, l.lg, dgam, dbet, L);
         dvs_store_tile(a.gout, dag, dh, L);
+        LBSTAMP(7);              // d h products, LayerNorm backward, store
     }
     __syncthreads();
+    LBSTAMP(8);                  // closing barrier
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     {
         // pass 1: the two 64x64 edge matrices; pass 2: node matrices + all vectors
@@ -212,6 +245,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
             slab[a.o_edge2_b] = s;
         }
     }
+    LBSTAMP(9);                  // slab epilogue
 }
 
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {

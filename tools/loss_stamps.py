@@ -27,3 +27,14 @@ names = ["staging + barrier", "tile load + LayerNorm", "node head", "U, V produc
 print("k_loss_fwd, cycles per wave and launch (2 DAGs per wave), mean over 256 workgroups")
 for k in range(6): print(f"  {names[k]:28s} wave 0 {t[:,0,k].mean():7.0f}   wave 4 {t[:,4,k].mean():7.0f}")
 print(f"  {'sum':28s} {t[:,0,:].sum(1).mean():7.0f} {t[:,4,:].sum(1).mean():7.0f}")
+
+fb = lib.dvs_debug_read_stamps_lossb; fb.restype = ctypes.c_int; fb.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+bufb = np.zeros(256*4*12, np.uint64); fb(bufb.ctypes.data, bufb.nbytes, 1)
+train_batch(f, model, opt); torch.cuda.synchronize()
+fb(bufb.ctypes.data, bufb.nbytes, 0)
+t = bufb.reshape(256, 4, 12).astype(np.float64)
+names = ["staging + barrier + init", "tile load + LN + transpose", "node head fwd + bwd", "U, V recompute + park", "pass 1 (i walks j)",
+         "pass 2 (j walks i)", "transposes + dWa, dWb", "d h products, LN backward, store", "closing barrier", "slab epilogue"]
+print("k_loss_bwd, cycles per wave and launch (4 DAGs per wave), mean over 256 workgroups")
+for k in range(10): print(f"  {names[k]:34s} wave 0 {t[:,0,k].mean():7.0f}   wave 3 {t[:,3,k].mean():7.0f}")
+print(f"  {'sum':34s} {t[:,0,:].sum(1).mean():7.0f} {t[:,3,:].sum(1).mean():7.0f}")

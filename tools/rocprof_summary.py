@@ -15,7 +15,14 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")
+    name = name.split("(")[0].replace("void ", "")
+    if name.startswith("_Z"):            # a name rocprofv3 could not demangle (_Float16-style types in the signature): _Z<len><name>...
+        i = 2
+        while i < len(name) and name[i].isdigit():
+            i += 1
+        if i > 2:
+            name = name[i:i + int(name[2:i])]
+    return name
 
 
 def kernels(db):

@@ -217,3 +217,8 @@ void dvs_launch_loss_fwd_w(const LossArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_embed_bwd_w(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
 void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_loss_bwd_w(const LossArgs& a, int grid, dvs_stream_t st);
+
+// one output tile (16 features ot) of a T-layout product, parked row-major: rows tok0 + r, columns 16 ot + 4g ..
+__device__ __forceinline__ void dvs_park_col(float* buf, int tok0, int ot, const f4& v, const Lane& L) {
+    *(f4*)(buf + (tok0 + L.r) * DVS_LD + 16 * ot + 4 * L.g) = v;
+}

@@ -3,26 +3,31 @@
 // owns tile w of the workgroup's current DAG and accumulates weight gradients in MFMA accumulators exactly like the
 // one-tile kernels; the workgroup's waves are added in fixed order through LDS and written to the workgroup's slab.
 #include "dvs_wide.h"
+#include "dvs_wimg.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // Attention-core backward, wide: d(pre) -> d q, d k, d v projections (frag tiles, natural feature order) and dWo, dbo.
 // Nothing but the sublayer input was saved: q, k, v and the probabilities are recomputed.
-//   wave w   : x -> q,k,v parked in LDS; dy = dropout-mask(d pre); dO^T = Wo^T dy parked          | barrier
+//   stage 1  : x -> q,k,v (bf16x3 from the per-step images: waves 0..2NT-1 = (tile, half of the in-projection rows)) and
+//              dO^T = Wo^T dropout-mask(d pre) (the remaining waves, by output tile), parked in LDS   | barrier
 //   phase A  : thread (i, h): row statistics (lse, delta), O_i (for dWo), dq_i                     | barrier
 //   phase B  : thread (j, h): walks the queries i that may attend j; dk_j, dv_j in registers       | barrier
 //              dk, dv overwrite the K, V buffers                                                    | barrier
 //   wave w   : stores dq, dk, dv tiles; dWo += dy(N)^T O(N) in MFMA accumulators                  | barrier
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWBLds {
-    float *Win, *Wout, *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
+    dvs_bf16 *WoTh, *WoTl, *Winh, *Winl;     // bf16x3 pairs, in the order of the per-step block (dvs_wimg.h: WoutT, WinB)
+    float *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
     uint64_t* al;                // [3][48] ancestor bit-rows (whom token i attends), their even / odd set bits
     uint64_t* de;                // [3][48] descendant bit-rows (who attends token j), likewise
 };
 __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     AttnWBLds l;
-    l.Win = (float*)smem;
-    l.Wout = l.Win + 192 * DVS_LD;
-    l.inb = l.Wout + 64 * DVS_LD;
+    l.WoTh = (dvs_bf16*)smem;
+    l.WoTl = l.WoTh + 64 * DVS_LDB;
+    l.Winh = l.WoTl + 64 * DVS_LDB;
+    l.Winl = l.Winh + 192 * DVS_LDB;
+    l.inb = (float*)(l.Winl + 192 * DVS_LDB);
     l.outb = l.inb + 192;
     l.lg = l.outb + 64;
     l.lb = l.lg + 64;
@@ -38,14 +43,13 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     l.de = l.al + 3 * DVS_WTOK;
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 256 * DVS_LD + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 12 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 12 * DVS_WTOK;
 
 // 8 waves: waves 0..NT-1 own the tiles (MFMA parts, dWo accumulators), all 8 share the items of phases A and B.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnWBLds l = attnwb_lds(smem);
-    dvs_stage_matrix(l.Win, DVS_LD, a.in_w, 64, 192, 64);
-    dvs_stage_matrix(l.Wout, DVS_LD, a.out_w, 64, 64, 64);
+    dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(8 * DVS_IMG64));     // WoutT pair, Win hi / mid
     dvs_stage_vector(l.inb, a.in_b, 192);
     dvs_stage_vector(l.outb, a.out_b, 64);
     if (a.ln.stats) {
@@ -59,6 +63,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     const int N = a.dims.N, NT = a.dims.NT, NTOK = 16 * NT, B = a.dims.B;
     const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
     const bool has_tile = L.wave < NT;
+    const int pw = L.wave >> 1, phalf = L.wave & 1;              // stage 1: (tile, half of the in-projection rows)
+    const bool proj = L.wave < 2 * NT;
     const float scale = 0.35355339059327373f;
     f4 aWo[4][4];
 #pragma unroll
@@ -80,37 +86,59 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             l.al[DVS_WTOK + i] = e;
             l.al[2 * DVS_WTOK + i] = o;
         }
-        f4 dy[4];
-        if (has_tile) {
+        // ---- stage 1: all 8 waves, bf16x3 (q, k, v feed a softmax, dO is a gradient product: smooth, as in the one-tile backward) ----
+        if (proj) {
+            const size_t ptile = (size_t)dag * NT + pw;
+            const int ptok0 = 16 * pw, pNl = dvs_rows_of(N, pw);
             f4 x[4], kv[4], dummy[4];
             float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
+            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, ptile, pNl, L);
             if (a.kv) {
-                dvs_load_tile(kv, a.kv, tile, L);
+                dvs_load_tile(kv, a.kv, ptile, L);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) kv[t] = x[t];
             }
-            f4 q[4], k[4], v[4];
+            const SplitT kvs = dvs_split_T(kv);
+            if (phalf == 0) {
+                f4 q[4], k01[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                q[t] = dvs_vecT(l.inb, t, L);
-                k[t] = dvs_vecT(l.inb + 64, t, L);
-                v[t] = dvs_vecT(l.inb + 128, t, L);
+                for (int t = 0; t < 4; ++t) q[t] = dvs_vecT(l.inb, t, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) k01[t] = dvs_vecT(l.inb + 64, t, L);
+                dvs_matb_T<4>(q, dvs_split_T(x), l.Winh, l.Winl, 0, L);
+                dvs_matb_T<2>(k01, kvs, l.Winh, l.Winl, 64, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dvs_park_col(l.Q, ptok0, t, q[t] * scale, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, t, k01[t], L);
+            } else {
+                f4 k23[2], v[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) k23[t] = dvs_vecT(l.inb + 96, t, L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = dvs_vecT(l.inb + 128, t, L);
+                dvs_matb_T<2>(k23, kvs, l.Winh, l.Winl, 96, L);
+                dvs_matb_T<4>(v, kvs, l.Winh, l.Winl, 128, L);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, 2 + t, k23[t], L);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dvs_park_col(l.V, ptok0, t, v[t], L);
             }
-            dvs_mat_T<4, 4>(q, x, l.Win, DVS_LD, 0, L);
-            dvs_mat_T<4, 4>(k, kv, l.Win, DVS_LD, 64, L);
-            dvs_mat_T<4, 4>(v, kv, l.Win, DVS_LD, 128, L);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] *= scale;
-            dvs_park_T(l.Q + tok0 * DVS_LD, q, L);
-            dvs_park_T(l.K + tok0 * DVS_LD, k, L);
-            dvs_park_T(l.V + tok0 * DVS_LD, v, L);
-            dvs_load_grad(dy, a.gpre, tile, Nl, L);
-            dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
-            f4 dOT[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-            dvs_mat_Tt<4, 4>(dOT, dy, l.Wout, DVS_LD, 0, L);
-            dvs_park_T(l.DO + tok0 * DVS_LD, dOT, L);
+        } else {
+            // dO^T of every tile, output tiles ot = dw, dw + ndw, .. of each (ndw = 8 - 2 NT waves share them)
+            const int dw = L.wave - 2 * NT, ndw = 8 - 2 * NT;
+            for (int tw = 0; tw < NT; ++tw) {
+                f4 dyt[4];
+                dvs_load_grad(dyt, a.gpre, (size_t)dag * NT + tw, dvs_rows_of(N, tw), L);
+                dvs_dropout_tile(dyt, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, 16 * tw);
+                const SplitT ds = dvs_split_T(dyt);
+                for (int ot = dw; ot < 4; ot += ndw) {
+                    f4 o1[1] = {f4_zero()};
+                    dvs_matb_T<1>(o1, ds, l.WoTh, l.WoTl, 16 * ot, L);
+                    dvs_park_col(l.DO, 16 * tw, ot, o1[0], L);
+                }
+            }
         }
         __syncthreads();
         const DvsCoreItem it = dvs_core_item(N);          // (token, head[, half]) of this lane in phases A and B
@@ -246,6 +274,9 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
         __syncthreads();
         if (has_tile) {
             const bool valid = L.r < Nl;
+            f4 dy[4];                 // stage 1 computed dO on other waves: this tile's masked d pre again, for dWo / dbo
+            dvs_load_grad(dy, a.gpre, tile, Nl, L);
+            dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
             f4 g[4];
             dvs_lds_T(g, l.DQ, tok0, L);
 #pragma unroll

@@ -241,10 +241,6 @@ __device__ __forceinline__ AttnWLds attnw_lds(char* smem) {
 }
 constexpr size_t ATTNW_BYTES = 3 * 256 * DVS_LDB * sizeof(dvs_bf16) + (192 + 64 + 128 + 3 * (size_t)DVS_WSCR) * 4 + DVS_WTOK * 8;
 
-// one output tile (16 features ot) of a T-layout product, parked row-major: rows tok0 + r, columns 16 ot + 4g ..
-__device__ __forceinline__ void dvs_park_col(float* buf, int tok0, int ot, const f4& v, const Lane& L) {
-    *(f4*)(buf + (tok0 + L.r) * DVS_LD + 16 * ot + 4 * L.g) = v;
-}
 
 #ifdef DVS_STAMPS
 __device__ unsigned long long dvs_stamps_w[256 * 8 * 8];

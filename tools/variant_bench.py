@@ -17,8 +17,8 @@ runpy.run_path("bench.py", run_name="__main__")
 '''
 extra = []
 names = []
-for a in sys.argv[1:]:
-    (extra if a.startswith("--") or (extra and not a.isalpha() and a.isdigit()) else names).append(a)
+for a in sys.argv[1:]:                   # library names first, then bench.py's own arguments from the first "--..." on
+    (extra if extra or a.startswith("--") else names).append(a)
 for name in names:
     out = subprocess.run([sys.executable, "-c", CHILD % (name, extra)], capture_output=True, text=True)
     try:

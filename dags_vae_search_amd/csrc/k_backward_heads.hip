@@ -422,31 +422,44 @@ __global__ __launch_bounds__(512) void k_fc_dw(FcDwArgs a) {
         for (int t = 0; t < 4; ++t) acc[j][t] = f4_zero();
         acc3[j][0] = acc3[j][1] = f4_zero();
     }
+    // 16 DAGs per round: all 56 loads of the round first, none under a condition (`dv ? load : 0` made every contraction step a
+    // branch with its own memory round trip: 8 in a row per wave were most of this kernel's 21 us); rows beyond the part read
+    // DAG 0 and are zeroed by a multiply
     for (int c0 = d0; c0 < d1; c0 += 16) {
+        float ga[4][4], zb[4][2], xb[4][FC_MT], gm[4][FC_MT], live[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int d = c0 + 4 * ks + L.g;
             const bool dv = d < d1;
             const size_t dd = dv ? d : 0;
-            float ga[4], zb[2], xb[FC_MT], gm[FC_MT];
+            live[ks] = dv ? 1.f : 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ga[t] = dv ? a.gz[dd * 64 + 16 * t + L.r] : 0.f;
+            for (int t = 0; t < 4; ++t) ga[ks][t] = a.gz[dd * 64 + 16 * t + L.r];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) zb[t] = dv ? a.z[dd * 32 + 16 * t + L.r] : 0.f;
+            for (int t = 0; t < 2; ++t) zb[ks][t] = a.z[dd * 32 + 16 * t + L.r];
 #pragma unroll
             for (int j = 0; j < FC_MT; ++j) {
-                xb[j] = dv ? a.xenc[dd * dstride + 16 * (FC_MT * mg + j) + L.r] : 0.f;
-                gm[j] = dv ? a.gmem[dd * dstride + 16 * (FC_MT * mg + j) + L.r] : 0.f;
-                bs3[j] += gm[j];
+                xb[ks][j] = a.xenc[dd * dstride + 16 * (FC_MT * mg + j) + L.r];
+                gm[ks][j] = a.gmem[dd * dstride + 16 * (FC_MT * mg + j) + L.r];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ga[ks][t] *= live[ks];
+#pragma unroll
+            for (int j = 0; j < FC_MT; ++j) {
+                gm[ks][j] *= live[ks];
+                bs3[j] += gm[ks][j];
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bsfc[t] += ga[t];
+            for (int t = 0; t < 4; ++t) bsfc[t] += ga[ks][t];
 #pragma unroll
             for (int j = 0; j < FC_MT; ++j) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[j][t] = dvs_mfma(ga[t], xb[j], acc[j][t]);
+                for (int t = 0; t < 4; ++t) acc[j][t] = dvs_mfma(ga[ks][t], xb[ks][j], acc[j][t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc3[j][t] = dvs_mfma(gm[j], zb[t], acc3[j][t]);
+                for (int t = 0; t < 2; ++t) acc3[j][t] = dvs_mfma(gm[ks][j], zb[ks][t], acc3[j][t]);
             }
         }
     }

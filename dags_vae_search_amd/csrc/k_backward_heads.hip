@@ -142,49 +142,72 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         dvs_wave_sync();
         const unsigned par = rec->parents[(L.r + 1) & 15];
         LBSTAMP(3);              // U, V recompute + park
-        // pass 1: lane r = i walks j; accumulates dU, dw2, db2; publishes d logit(i, j)
-#pragma unroll 2
-        for (int j = 0; j < N - 2; ++j) {
-            f4 pre[4];
-            float e = 0.f;
+        // Both passes are vector-instruction bound on one wave per SIMD, so they are written for instruction count: whole-f4
+        // arithmetic (v_pk_add / v_pk_fma), w2 factored out of the dU / dV sums (dU = w2 * sum_j dl_j step(pre_j)), and the ReLU
+        // derivative as a clamped multiply, step(x) = clamp(x * 1e30, 0, 1) — one instruction instead of compare + select; it
+        // differs from (x > 0) only for 0 < x < 1e-30, far below the 1e-6 at which device and oracle can disagree on a unit.
+        // pass 1: lane r = i walks j; accumulates sU (-> dU), dw2, db2; publishes d logit(i, j)
+        f4 sU[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, sV[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+        // two j per iteration, written out (hipcc does not unroll this loop on request): the chain LDS read -> 48 vector
+        // instructions -> cross-lane sum -> exp -> reciprocal -> 32 more runs twice side by side; an odd last j repeats j - 1
+        // with d logit forced to zero
+        for (int j0 = 0; j0 < N - 2; j0 += 2) {
+            f4 pre[2][4], ev[2] = {f4_zero(), f4_zero()};
+            const bool has2 = j0 + 1 < N - 2;
+            const int jj[2] = {j0, has2 ? j0 + 1 : j0};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f4 vj = *(const f4*)(scrV + j * DVS_LD + 16 * t + 4 * L.g);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    pre[t][kk] = fmaxf(U[t][kk] + vj[kk], 0.f);
-                    e += w2v[t][kk] * pre[t][kk];
+                for (int t = 0; t < 4; ++t) {
+                    const f4 x = U[t] + *(const f4*)(scrV + jj[u] * DVS_LD + 16 * t + 4 * L.g);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) pre[u][t][kk] = fmaxf(x[kk], 0.f);
+                    ev[u] += w2v[t] * pre[u][t];
                 }
+            float dl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float logit = dvs_sum_g((ev[u][0] + ev[u][1]) + (ev[u][2] + ev[u][3])) + b2;
+                const bool pv = (L.r > jj[u]) && (L.r <= N - 2) && (u == 0 || has2);
+                const float truth = (float)((par >> (jj[u] + 1)) & 1u);
+                const float sg = 1.0f / (1.0f + __expf(-logit));
+                dl[u] = pv ? gr * (sg - truth) : 0.f;
             }
-            const float logit = dvs_sum_g(e) + b2;
-            const bool pv = (L.r > j) && (L.r <= N - 2);
-            const float truth = (float)((par >> (j + 1)) & 1u);
-            const float sg = 1.0f / (1.0f + __expf(-logit));
-            const float dl = pv ? gr * (sg - truth) : 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    dw2[t][kk] += dl * pre[t][kk];
-                    dU[t][kk] += pre[t][kk] > 0.f ? dl * w2v[t][kk] : 0.f;
+                for (int t = 0; t < 4; ++t) {
+                    dw2[t] += pre[u][t] * dl[u];
+                    f4 st;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(pre[u][t][kk] * 1.0e30f, 0.f), 1.f);
+                    sU[t] += st * dl[u];
                 }
             if (L.g == 0) {
-                db2 += dl;
-                dlm[L.r * 16 + j] = dl;
+                db2 += dl[0] + dl[1];
+                dlm[L.r * 16 + j0] = dl[0];
+                if (has2) dlm[L.r * 16 + j0 + 1] = dl[1];
             }
         }
         dvs_wave_sync();
         LBSTAMP(4);              // pass 1
-        // pass 2: lane r = j walks i; accumulates dV
+        // pass 2: lane r = j walks i; accumulates sV (-> dV)
 #pragma unroll 2
         for (int i = 1; i <= N - 2; ++i) {
             const float dl = (L.r < i) ? dlm[i * 16 + L.r] : 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const f4 ui = *(const f4*)(scrU + i * DVS_LD + 16 * t + 4 * L.g);
+                const f4 x = *(const f4*)(scrU + i * DVS_LD + 16 * t + 4 * L.g) + V[t];
+                f4 st;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dV[t][kk] += (ui[kk] + V[t][kk] > 0.f) ? dl * w2v[t][kk] : 0.f;
+                for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(x[kk] * 1.0e30f, 0.f), 1.f);
+                sV[t] += st * dl;
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dU[t] = w2v[t] * sU[t];
+            dV[t] = w2v[t] * sV[t];
         }
         dvs_wave_sync();
         LBSTAMP(5);              // pass 2

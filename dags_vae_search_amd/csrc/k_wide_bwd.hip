@@ -453,49 +453,57 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             // pass 1: lane r = token i walks j < i; accumulates dU, dw2, db2; publishes d logit(i, j)
             const uint64_t par = rec->parents[tok + 1 < DVS_WTOK ? tok + 1 : 0];
             const int jend = (N - 2 < tok0 + 15) ? N - 2 : tok0 + 15;
+            // written for instruction count, as k_loss_bwd's passes: f4 arithmetic, w2 factored out (dU = w2 * sU), the ReLU
+            // derivative as a clamped multiply
+            f4 sU[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
             for (int j = 0; j < jend; ++j) {
-                f4 pre[4];
-                float e = 0.f;
+                f4 pre[4], ev = f4_zero();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const f4 vj = *(const f4*)(l.V + j * DVS_LD + 16 * t + 4 * L.g);
+                    const f4 x = U[t] + *(const f4*)(l.V + j * DVS_LD + 16 * t + 4 * L.g);
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        pre[t][kk] = fmaxf(U[t][kk] + vj[kk], 0.f);
-                        e += w2v[t][kk] * pre[t][kk];
-                    }
+                    for (int kk = 0; kk < 4; ++kk) pre[t][kk] = fmaxf(x[kk], 0.f);
+                    ev += w2v[t] * pre[t];
                 }
-                const float logit = dvs_sum_g(e) + b2;
+                const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
                 const bool pv = (tok > j) && (tok <= N - 2);
                 const float truth = (float)((par >> (j + 1)) & 1ull);
                 const float sg = 1.0f / (1.0f + __expf(-logit));
                 const float dl = pv ? gr * (sg - truth) : 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    dw2[t] += pre[t] * dl;
+                    f4 st;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        dw2[t][kk] += dl * pre[t][kk];
-                        dU[t][kk] += pre[t][kk] > 0.f ? dl * w2v[t][kk] : 0.f;
-                    }
+                    for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(pre[t][kk] * 1.0e30f, 0.f), 1.f);
+                    sU[t] += st * dl;
+                }
                 if (L.g == 0) {
                     db2 += dl;
                     l.dlm[tok * DLD + j] = dl;
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dU[t] = w2v[t] * sU[t];
         }
         __syncthreads();
         if (has_tile) {
             // pass 2: lane r = token j walks i > j; accumulates dV
             const int i0 = tok0 + 1 > 1 ? tok0 + 1 : 1;
+            f4 sV[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
             for (int i = i0; i <= N - 2; ++i) {
                 const float dl = (tok < i) ? l.dlm[i * DLD + tok] : 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const f4 ui = *(const f4*)(l.U + i * DVS_LD + 16 * t + 4 * L.g);
+                    const f4 x = *(const f4*)(l.U + i * DVS_LD + 16 * t + 4 * L.g) + V[t];
+                    f4 st;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) dV[t][kk] += (ui[kk] + V[t][kk] > 0.f) ? dl * w2v[t][kk] : 0.f;
+                    for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(x[kk] * 1.0e30f, 0.f), 1.f);
+                    sV[t] += st * dl;
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dV[t] = w2v[t] * sV[t];
 #pragma unroll
             for (int t = 0; t < 4; ++t) dbe1[t] += dV[t];
             f4 dUN[4], dVN[4];

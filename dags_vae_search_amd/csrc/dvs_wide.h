@@ -44,17 +44,12 @@ __device__ __forceinline__ void dvs_lds_N(f4 (&x)[4], const float* buf, int tok0
     }
 }
 
+// 8-deep dot product as two packed multiply-adds and a 3-add tree (was a chain of 8 dependent FMAs: the lane walks of the wide
+// attention backward are latency- and issue-bound).  Phases A and B both go through this function: identical scores.
 __device__ __forceinline__ float dvs_dot8(const f4& a0, const f4& a1, const float* p) {
     const f4 b0 = *(const f4*)p, b1 = *(const f4*)(p + 4);
-    float s = a0[0] * b0[0];
-    s = fmaf(a0[1], b0[1], s);
-    s = fmaf(a0[2], b0[2], s);
-    s = fmaf(a0[3], b0[3], s);
-    s = fmaf(a1[0], b1[0], s);
-    s = fmaf(a1[1], b1[1], s);
-    s = fmaf(a1[2], b1[2], s);
-    s = fmaf(a1[3], b1[3], s);
-    return s;
+    const f4 m = a1 * b1 + a0 * b0;
+    return (m[0] + m[1]) + (m[2] + m[3]);
 }
 
 // ---- attention-core item layout ------------------------------------------------------------------------------------------

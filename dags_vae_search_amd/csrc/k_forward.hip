@@ -36,10 +36,36 @@ __global__ __launch_bounds__(8 * 16 * PACK_DAGS) void k_pack(PackArgs a) {
     float* s_adj = s_pos + PACK_DAGS * 16 * 16;
     float* s_msk = s_adj + PACK_DAGS * 16 * 16;        // [PACK_DAGS][8][N][N] bytes, streamed as floats
     // DAG dag0's blocks start at multiples of PACK_DAGS = 4 DAGs * {N*C, N*N} floats (8*N*N mask bytes): multiples of 16 bytes
-    pack_stream(s_lab, a.lab1h + (size_t)dag0 * N * C, (size_t)nd * N * C);
-    pack_stream(s_pos, a.pos1h + (size_t)dag0 * N * N, (size_t)nd * N * N);
-    pack_stream(s_adj, a.adj + (size_t)dag0 * N * N, (size_t)nd * N * N);
-    pack_stream(s_msk, (const float*)(a.tmask + (size_t)dag0 * 8 * N * N), (size_t)nd * 8 * N * N / 4);
+    // the four ranges in ONE batch of loads (four pack_stream calls in a row were four memory round trips for ~2 loads per lane)
+    {
+        const float* src[4] = {a.lab1h + (size_t)dag0 * N * C, a.pos1h + (size_t)dag0 * N * N, a.adj + (size_t)dag0 * N * N,
+                               (const float*)(a.tmask + (size_t)dag0 * 8 * N * N)};
+        float* dst[4] = {s_lab, s_pos, s_adj, s_msk};
+        const int nf[4] = {nd * N * C, nd * N * N, nd * N * N, nd * 8 * N * N / 4};
+        bool whole = true;                                        // every range a whole number of 16-byte pieces, <= 2 per lane
+#pragma unroll
+        for (int k = 0; k < 4; ++k) whole = whole && (nf[k] & 3) == 0 && (nf[k] >> 2) <= 2 * (int)blockDim.x;
+        if (whole) {
+            f4 v[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = (int)threadIdx.x + u * (int)blockDim.x;
+                    v[k][u] = *(const f4*)(src[k] + 4 * (i < (nf[k] >> 2) ? i : 0));
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = (int)threadIdx.x + u * (int)blockDim.x;
+                    if (i < (nf[k] >> 2)) *(f4*)(dst[k] + 4 * i) = v[k][u];
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pack_stream(dst[k], src[k], (size_t)nf[k]);
+        }
+    }
     __syncthreads();
     // thread = (head h, DAG d, token i): head 0 builds the record row, heads 1..7 check that their mask copy equals head 0's
     const int h = threadIdx.x / (16 * PACK_DAGS), d = (threadIdx.x >> 4) % PACK_DAGS, i = threadIdx.x & 15;

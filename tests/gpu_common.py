@@ -44,4 +44,4 @@ def smoke_check():
     assert rel(total.item(), t.detach()) < 1e-4, (total.item(), float(t))
     for name, p in model.named_parameters():
         ref = P[name].grad
-        assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * max(ref.abs().max().item(), 1e-3), name
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * max(ref.abs().max().item(), 1e-3), name      # the parity tests' bound

@@ -43,9 +43,10 @@ print("DIGEST", h.hexdigest(), loss_value)
 """
 
 
-def run_child(split: bool) -> str:
+def run_child(split: bool, latent_kernels: bool = False) -> str:
     env = dict(os.environ)
     env["DVS_SPLIT_STACK"] = "1" if split else "0"
+    env["DVS_LATENT_KERNELS"] = "1" if latent_kernels else "0"
     out = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
@@ -53,5 +54,8 @@ def run_child(split: bool) -> str:
 
 
 def test_chained_and_split_launches_agree_bitwise():
-    chained, split = run_child(False), run_child(True)
+    """also: the latent block as phases of the encoder chains (default) against its own kernels inside otherwise chained
+    launches (DVS_LATENT_KERNELS=1) — the 1000-DAG batch leaves the chains' last MFMA group half empty"""
+    chained, split, own_latent = run_child(False), run_child(True), run_child(False, latent_kernels=True)
     assert chained == split
+    assert chained == own_latent

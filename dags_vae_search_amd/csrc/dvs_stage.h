@@ -3,9 +3,10 @@
 // (biases, LayerNorm parameters; optionally permuted by dvs_pi) — described as data, so that the PREVIOUS phase can fetch
 // it while its own tail runs:
 //
-//     phase p:   [DAG loop] -> issue(plan of p+1): global loads into registers, nothing waits for them
-//                -> workgroup barrier -> epilogue of p (gradient slabs; uses LDS) -> workgroup barrier
-//                -> commit(plan of p+1): registers -> LDS                                  -> workgroup barrier
+//     phase p:   [DAG loop] -> older wave group: issue(plan of p+1): global loads into registers, nothing waits for them
+//                -> workgroup barrier (every wave is done with p's images)
+//                -> younger group: epilogue of p (gradient partials through LDS above DVS_BWD_EPI_FLOOR, dvs_bwd_phases.h)
+//                   older group:   commit(plan of p+1): registers -> LDS below that floor    -> workgroup barrier
 //     phase p+1: [DAG loop] ...
 //
 // Round 1 staged every phase's images behind the closing barrier of the phase before: 5-9 k cycles per phase (8-15 % of a
@@ -34,7 +35,7 @@ struct DvsStagePlan {
     int phase;                         // index of the phase inside its chained launch (diagnostic stamps, tools/phase_stamps.py)
 };
 
-// Diagnostic build only (make STAMPS=1 -> libdvs_hip_stamps.so, never shipped or loaded by the package): lane 0 of every
+// Diagnostic build only (make stamps -> libdvs_hip_stamps.so, never shipped or loaded by the package): lane 0 of every
 // wave records s_memtime at fixed points of every phase; tools/phase_stamps.py turns them into a per-phase time budget.
 #ifdef DVS_STAMPS
 constexpr int DVS_STAMP_IDS = 8, DVS_STAMP_PHASES = 32, DVS_STAMP_WAVES = 8, DVS_STAMP_WGS = 256;

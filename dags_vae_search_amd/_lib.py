@@ -19,7 +19,7 @@ TILE_TOKENS = 16
 DECODE_STATE_BYTES = 440
 RECORD_BYTES = 96         # one-tile path; record_bytes(lib, shape) gives the size that applies
 LOSS_FLOATS = 5           # DVS_LOSS_FLOATS: total, recon, kld, non-finite flag, invalid-features flag
-ABI_VERSION = 200         # DVS_VERSION of include/dvs.h this binding was written against
+ABI_VERSION = 201         # DVS_VERSION of include/dvs.h this binding was written against
 
 
 class DvsShape(Structure):
@@ -57,6 +57,10 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, eps, status, losses, mu, logvar, stream)
     lib.dvs_loss_forward.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dvs_loss_forward_notify.restype = c_int
+    # (... as dvs_loss_forward ..., logvar, host_tail (pinned, 8 words), host_seq, stream)
+    lib.dvs_loss_forward_notify.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p]
     lib.dvs_loss_backward.restype = c_int
     # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, gcoef, grads, stream)
     lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
@@ -99,7 +103,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_forward_notify", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
            "dvs_clip_adam", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
 
 

@@ -767,6 +767,14 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
 extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
                                 int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps,
                                 const int32_t* status, float* losses, float* mu, float* logvar, void* stream) {
+    return dvs_loss_forward_notify(s, records, records_bytes, params, n_params, workspace, workspace_bytes, eps,
+                                   (int32_t*)status, losses, mu, logvar, nullptr, 0u, stream);     // no host_tail: status is only read
+}
+
+extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
+                                       int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps,
+                                       int32_t* status, float* losses, float* mu, float* logvar, void* host_tail,
+                                       uint32_t host_seq, void* stream) {
     if (int e = check_shape(s)) return e;
     if (!records || !params || !workspace || !losses) return fail(10, "dvs_loss_forward: null pointer");
     if (int e = check_buffers(s, "dvs_loss_forward", true, records_bytes, true, n_params, true, workspace_bytes)) return e;
@@ -810,6 +818,8 @@ extern "C" int dvs_loss_forward(const dvs_shape* s, const void* records, size_t 
     fa.dag_loss = ws + W.dag_loss;
     fa.status = status;
     fa.losses = losses;
+    fa.host_tail = (float*)host_tail;
+    fa.host_seq = host_seq;
     dvs_launch_finalize(fa, st);
     const size_t nb = (size_t)d.B * 32 * sizeof(float);
 #ifdef DVS_EMU

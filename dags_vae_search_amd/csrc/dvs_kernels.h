@@ -99,8 +99,10 @@ struct FinalizeArgs {
     int B;
     float beta;
     const float* dag_loss;
-    const int* status;           // optional validation word of the pack / build call
+    int* status;                 // optional validation word of the pack / build call (re-armed when host_tail is given)
     float* losses;               // [DVS_LOSS_FLOATS]
+    float* host_tail;            // optional pinned host words [8] (include/dvs.h: dvs_loss_forward_notify)
+    uint32_t host_seq;
 };
 
 struct BuildArgs {

@@ -21,6 +21,8 @@ import copy
 import math
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -101,6 +103,9 @@ class _PaceLoss(torch.autograd.Function):
         model._engine.loss_backward(ctx.shape, model.flat_params, gcoef, flat)
         grads = [flat[off:off + n].view(shp) for (_, off, shp), n in zip(model._engine.table, model._numels)]
         return (None, None, None, *grads)
+
+
+_EARLY_READ_MODE = os.environ.get("DVS_EARLY_READ", "poll")      # "event": the side-stream copy behind an event (A/B, data parallel)
 
 
 class PaceVaeV3(nn.Module):
@@ -354,6 +359,19 @@ class PaceVaeV3(nn.Module):
         copy is already in flight on the side stream (wait for its event); otherwise it is issued here, at the end of the
         step (data-parallel steps: the loss scalars are only global after the all-reduce).
         Returns (list of 5 floats, rank-local status bits)."""
+        if self._early_pending == "poll":
+            self._early_pending = False
+            words = self._host_tail.numpy().view("uint32")          # pinned memory, re-read on every access
+            seq, spins = self._host_seq, 0
+            while int(words[7]) != seq:
+                spins += 1
+                if spins > 2_000_000:                               # ~seconds: the forward never takes that long; fail loudly
+                    torch.cuda.current_stream().synchronize()
+                    if int(words[7]) != seq:
+                        raise RuntimeError("the device never signalled the end of the forward (dvs_loss_forward_notify)")
+            vals = self._host_tail.tolist()
+            self._early_scalars = torch.tensor(vals[:5])            # the caller's recon / kld (host tensors on this path)
+            return vals[:5], int(words[5])
         if self._early_pending:
             self._early_pending = False
             self._ev_tail.synchronize()
@@ -467,8 +485,9 @@ class PaceVaeV3(nn.Module):
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
             self.bind_flat_grads()        # first step: allocate (also hands the validation word to the engine)
         if self._early_pending:           # a step whose read_step() never came (exception in between): drain it first, so
-            self._early_pending = False   # that its re-arming of the validation word cannot land behind this step's pack
-            self._ev_tail.synchronize()
+            pending, self._early_pending = self._early_pending, False   # that its re-arming of the validation word cannot land
+            if pending != "poll":                                       # behind this step's pack (the polled variant re-arms
+                self._ev_tail.synchronize()                             # on the main stream itself: ordered already)
         if not packed:
             # defer_check: the validation word is read (and re-armed) by read_step() at the end of the step
             self._pack(features, check=False if defer_check else None, zero_status=not defer_check)
@@ -476,9 +495,18 @@ class PaceVaeV3(nn.Module):
         shape = self._shape(B, beta)
         grads = self.flat_grads
         losses = self._step_losses            # tail of the gradient allocation (see bind_flat_grads); rewritten each step
-        eng.loss_forward(shape, self.flat_params, eps, losses)
+        # early read, one GPU: the kernel that reduces the losses writes the scalars, the validation word and — last — this step's
+        # sequence number into pinned host memory (dvs_loss_forward_notify); read_step() polls for it.  No event and no copy on
+        # any stream: an event recorded between the forward and the backward cost the main stream ~12 us per step.
+        notify = early_read and not group and self._host_tail.is_pinned() and _EARLY_READ_MODE != "event"
+        if notify:
+            self._host_seq = (getattr(self, "_host_seq", 0) + 1) & 0x7FFFFFFF or 1
+            eng.loss_forward(shape, self.flat_params, eps, losses, host_tail=self._host_tail, host_seq=self._host_seq)
+            self._early_pending = "poll"
+        else:
+            eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
-        if early_read:
+        if early_read and not notify:
             self._early_read(group, reduce_group)
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DVS_VERSION 200
+#define DVS_VERSION 201
 #define DVS_NUM_PARAMS 108
 #define DVS_RECORD_BYTES 96          /* one-tile path */
 #define DVS_RECORD_BYTES_WIDE 864    /* wide path; dvs_record_bytes(shape) returns the one that applies */
@@ -105,6 +105,16 @@ int dvs_build_records(const dvs_shape* s, const uint8_t* labels, const void* pre
 int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
                      void* workspace, size_t workspace_bytes, const float* eps, const int32_t* status, float* losses,
                      float* mu, float* logvar, void* stream);
+
+/* dvs_loss_forward that also tells the HOST when the loss scalars are final, without an event or a copy on any stream (ABI 201).
+ * host_tail: 8 x 4 bytes of pinned, device-mapped host memory (hipHostMalloc / torch pin_memory).  The kernel that reduces the
+ * per-DAG losses writes [0..4] = losses[0..4], [5] = the validation word *status (int32 bits; 0 without status), [6] = 0, then —
+ * behind a system-scope fence — [7] = host_seq (uint32).  A host that polls [7] for the value it passed reads final scalars
+ * where the reference's `loss.item()` returns (experiments/03_synthetic_12/main.py:104), while backward and optimiser are still
+ * queued.  With host_tail the validation word is RE-ARMED (*status = 0) once it has been read; status is written in that case. */
+int dvs_loss_forward_notify(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
+                            int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps, int32_t* status,
+                            float* losses, float* mu, float* logvar, void* host_tail, uint32_t host_seq, void* stream);
 
 /* Backward of the same step (autograd of pace.py:1974-2035; experiments/03_synthetic_12/main.py:114).  Must follow
  * dvs_loss_forward on the same workspace and parameters: it reads the forward's saved activations and per-step weight images.

@@ -207,6 +207,7 @@ inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __threadfence() {}
 inline void __threadfence_block() {}
+inline void __threadfence_system() {}
 #define __builtin_amdgcn_fence(...) ((void)0)
 
 // ---- atomics (blocks run on several OS threads) -------------------------------------------------------

@@ -554,3 +554,36 @@ def test_data_parallel_step_over_rccl_world1_equals_single_gpu_step(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_host_notification_carries_the_same_scalars_as_the_device_tail():
+    """dvs_loss_forward_notify (the fused single-GPU step's early read): the pinned host words polled by read_step() equal the
+    device-side tail bit for bit, the sequence word advances by one per step, the validation word is re-armed by the kernel,
+    and an invalid batch still reaches the host (status bits) and the device guard (no update)."""
+    from dags_vae_search_amd import optim as dopt
+    from dags_vae_search_amd.train import train_batch
+    cfg, params, graphs, z = load_golden("n12c12")
+    model = build_model(cfg, params).train()
+    opt = dopt.Adam(model.parameters(), lr=1e-4).attach(model)
+    f = feats_for(model, graphs)
+    model.seed(3)
+    seqs = []
+    for _ in range(3):
+        loss_value, recon, kld = train_batch(f, model, opt)
+        torch.cuda.synchronize()
+        dev = model._step_tail.cpu()
+        host = model._host_tail
+        assert torch.equal(host[:5], dev[:5]) and loss_value == float(dev[0])
+        assert float(recon) == float(dev[1]) and float(kld) == float(dev[2])
+        assert int(model._step_status.item()) == 0                      # re-armed on the device
+        seqs.append(int(host.numpy().view("uint32")[7]))
+    assert seqs == [seqs[0], seqs[0] + 1, seqs[0] + 2]
+    before = model.flat_params.clone()
+    bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in f.items()}
+    key = next(k for k, v in bad.items() if torch.is_tensor(v) and v.dim() == 3 and v.dtype == torch.float32)
+    bad[key][0, 0, :] = 0.5                                             # not one-hot any more
+    with pytest.raises(ValueError):
+        train_batch(bad, model, opt)
+    torch.cuda.synchronize()
+    assert torch.equal(before, model.flat_params)
+    train_batch(f, model, opt)                                          # and the next valid step goes through

@@ -151,8 +151,9 @@ class PaceEngine:
     def loss_forward(self, shape, params: torch.Tensor, eps: Optional[torch.Tensor], losses: torch.Tensor,
                      mu: Optional[torch.Tensor] = None, logvar: Optional[torch.Tensor] = None,
                      host_tail: Optional[torch.Tensor] = None, host_seq: int = 0):
-        """host_tail (8 pinned float32 words) + host_seq: the device writes the final scalars / validation word there and the
-        sequence number last (include/dvs.h: dvs_loss_forward_notify); the validation word is re-armed by the same kernel."""
+        """host_tail (pinned float32 words, the first four are used) + host_seq (24 bits): the device writes [total, recon, kld,
+        (seq << 8) | flags | validation bits] there with one 16-byte store (include/dvs.h: dvs_loss_forward_notify) and re-arms
+        the validation word in the same kernel."""
         _require_cuda(params, "parameters")
         ws = self.workspace(shape.batch, params.device)
         if losses.numel() < dl.LOSS_FLOATS:
@@ -163,11 +164,11 @@ class PaceEngine:
                                                          _ptr(self._status), _ptr(losses), _ptr(mu), _ptr(logvar), _stream()),
                      "dvs_loss_forward")
             return
-        if not host_tail.is_pinned() or host_tail.numel() < 8 or host_tail.dtype != torch.float32:
-            raise ValueError("host_tail must be 8 pinned float32 words")
+        if not host_tail.is_pinned() or host_tail.numel() < 4 or host_tail.dtype != torch.float32 or host_tail.data_ptr() % 16:
+            raise ValueError("host_tail must be at least 4 pinned float32 words, 16-byte aligned")
         dl.check(self.lib, self.lib.dvs_loss_forward_notify(
             ctypes.byref(shape), _ptr(self._records), _nbytes(self._records), _ptr(params), params.numel(), _ptr(ws), _nbytes(ws),
-            _ptr(eps), _ptr(self._status), _ptr(losses), _ptr(mu), _ptr(logvar), host_tail.data_ptr(), int(host_seq) & 0xFFFFFFFF,
+            _ptr(eps), _ptr(self._status), _ptr(losses), _ptr(mu), _ptr(logvar), host_tail.data_ptr(), int(host_seq) & 0xFFFFFF,
             _stream()), "dvs_loss_forward_notify")
 
     def loss_backward(self, shape, params: torch.Tensor, gcoef: torch.Tensor, grads: torch.Tensor):

@@ -363,15 +363,16 @@ class PaceVaeV3(nn.Module):
             self._early_pending = False
             words = self._host_tail.numpy().view("uint32")          # pinned memory, re-read on every access
             seq, spins = self._host_seq, 0
-            while int(words[7]) != seq:
+            while int(words[3]) >> 8 != seq:                        # the device's ONE 16-byte store carries the sequence number
                 spins += 1
                 if spins > 2_000_000:                               # ~seconds: the forward never takes that long; fail loudly
                     torch.cuda.current_stream().synchronize()
-                    if int(words[7]) != seq:
+                    if int(words[3]) >> 8 != seq:
                         raise RuntimeError("the device never signalled the end of the forward (dvs_loss_forward_notify)")
-            vals = self._host_tail.tolist()
-            self._early_scalars = torch.tensor(vals[:5])            # the caller's recon / kld (host tensors on this path)
-            return vals[:5], int(words[5])
+            word = int(words[3])
+            vals = self._host_tail[:3].tolist() + [float((word >> 6) & 1), float((word >> 7) & 1)]
+            self._early_scalars = torch.tensor(vals)                # the caller's recon / kld (host tensors on this path)
+            return vals, word & 0x3F
         if self._early_pending:
             self._early_pending = False
             self._ev_tail.synchronize()
@@ -500,7 +501,7 @@ class PaceVaeV3(nn.Module):
         # any stream: an event recorded between the forward and the backward cost the main stream ~12 us per step.
         notify = early_read and not group and self._host_tail.is_pinned() and _EARLY_READ_MODE != "event"
         if notify:
-            self._host_seq = (getattr(self, "_host_seq", 0) + 1) & 0x7FFFFFFF or 1
+            self._host_seq = (getattr(self, "_host_seq", 0) + 1) & 0xFFFFFF or 1
             eng.loss_forward(shape, self.flat_params, eps, losses, host_tail=self._host_tail, host_seq=self._host_seq)
             self._early_pending = "poll"
         else:

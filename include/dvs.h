@@ -107,11 +107,12 @@ int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_byt
                      float* mu, float* logvar, void* stream);
 
 /* dvs_loss_forward that also tells the HOST when the loss scalars are final, without an event or a copy on any stream (ABI 201).
- * host_tail: 8 x 4 bytes of pinned, device-mapped host memory (hipHostMalloc / torch pin_memory).  The kernel that reduces the
- * per-DAG losses writes [0..4] = losses[0..4], [5] = the validation word *status (int32 bits; 0 without status), [6] = 0, then —
- * behind a system-scope fence — [7] = host_seq (uint32).  A host that polls [7] for the value it passed reads final scalars
- * where the reference's `loss.item()` returns (experiments/03_synthetic_12/main.py:104), while backward and optimiser are still
- * queued.  With host_tail the validation word is RE-ARMED (*status = 0) once it has been read; status is written in that case. */
+ * host_tail: 16 bytes (16-byte aligned) of pinned, device-mapped host memory (hipHostMalloc / torch pin_memory).  The kernel
+ * that reduces the per-DAG losses writes them with ONE 16-byte store: [0] total, [1] recon, [2] kld (f32), [3] a uint32 word
+ * = (host_seq << 8) | (invalid-features flag << 7) | (non-finite flag << 6) | (validation word *status & 0x3F).  A host that
+ * polls word [3] until its upper 24 bits equal the host_seq it passed (24 bits are kept), and reads [0..2] AFTER that, has final
+ * values where the reference's `loss.item()` returns (experiments/03_synthetic_12/main.py:104), while backward and optimiser
+ * are still queued.  With host_tail the validation word is RE-ARMED (*status = 0) once it has been read: status is written. */
 int dvs_loss_forward_notify(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
                             int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps, int32_t* status,
                             float* losses, float* mu, float* logvar, void* host_tail, uint32_t host_seq, void* stream);

@@ -5,7 +5,7 @@ LabeledDag (row codec).  All arithmetic runs in libdvs_hip.so (hand-written HIP 
 """
 from .features import LabeledDag, LabeledGraph, collate_graph_batch, pace_collate_fn, prepare_features  # noqa: F401
 from .pace import PaceVaeV3  # noqa: F401
-from .train import batch_test, load_model_state, train_batch, train_model  # noqa: F401
+from .train import batch_test, load_model_state, model_test, train_batch, train_model  # noqa: F401
 from . import optim  # noqa: F401
 from .records import CompactBatch, CompactDagDataset, encode_graphs  # noqa: F401
 from .bic import BNLearnWrapper  # noqa: F401

@@ -387,10 +387,11 @@ struct DvsDrop {
 // element index of (token, feature) within a [tokens][64] site: tok*64 + f; a lane's f4 covers features 16t+4g..+3
 // -> pair indices (tok*64 + 16t + 4g)/2 and +1.
 // tok0: token index of the tile's row 0 (0 on the one-tile path; 16 * tile-in-DAG on the wide path)
-__device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[4], uint32_t key, const DvsDrop& D, const Lane& L, int tok0 = 0) {
+template <int NTILE = 4>
+__device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[NTILE], uint32_t key, const DvsDrop& D, const Lane& L, int tok0 = 0) {
     if (!D.on) return;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTILE; ++t) {
         const uint32_t p0 = (uint32_t)((tok0 + L.r) * 64 + 16 * t + 4 * L.g) >> 1;
         const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
         x[t][0] = ((h0 & 0xFFFFu) >= D.thr16) ? x[t][0] * D.scale : 0.f;

@@ -331,18 +331,16 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
             dlabb[0] += dle[0];
             dlabb[1] += dle[1];
             // positional half
+            // the first dropout's mask as a tile of {0, scale}: drawn once, applied to the hidden here and to its gradient below
+            // (was two passes over the same 8 draws per lane); the second site covers 32 features: two tiles, not four
+            const uint32_t k1 = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site, gdag);
+            f4 m1[4] = {f4_splat(1.f), f4_splat(1.f), f4_splat(1.f), f4_splat(1.f)};
+            dvs_dropout_tile(m1, k1, D, L);
             f4 e1d[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) e1d[t] = e1[t];
-            const uint32_t k1 = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site, gdag);
-            dvs_dropout_tile(e1d, k1, D, L);
-            f4 de2[2];
-            {
-                f4 tmp[4] = {gx[2], gx[3], f4_zero(), f4_zero()};
-                dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L);
-                de2[0] = tmp[0];
-                de2[1] = tmp[1];
-            }
+            for (int t = 0; t < 4; ++t) e1d[t] = e1[t] * m1[t];
+            f4 de2[2] = {gx[2], gx[3]};
+            dvs_dropout_tile<2>(de2, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L);
             f4 e1dN[4], de2N[2], dleN[2];
             dvs_t2n<4>(e1dN, e1d, scr, L);
             dvs_t2n<2>(de2N, de2, scr, L);
@@ -350,7 +348,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
             dvs_outer_acc<4, 2>(dW2, e1dN, de2N);
             f4 de1[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
             dvs_mat_T<4, 2>(de1, de2, W2, EMB_LDW2, 0, L);
-            dvs_dropout_tile(de1, k1, D, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) de1[t] *= m1[t];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

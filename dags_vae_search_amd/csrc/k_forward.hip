@@ -277,8 +277,8 @@ __global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a, DvsStagePlan pl
                 }
             }
             {
-                f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
-                dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L);
+                f4 tmp[2] = {e2[0], e2[1]};
+                dvs_dropout_tile<2>(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L);
                 x[2] = tmp[0];
                 x[3] = tmp[1];
             }

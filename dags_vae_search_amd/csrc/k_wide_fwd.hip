@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void k_embed_fwd_w(EmbedArgs a) {
             }
         }
         {
-            f4 tmp[4] = {e2[0], e2[1], f4_zero(), f4_zero()};
-            dvs_dropout_tile(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L, T.tok0);
+            f4 tmp[2] = {e2[0], e2[1]};
+            dvs_dropout_tile<2>(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L, T.tok0);
             x[2] = tmp[0];
             x[3] = tmp[1];
         }

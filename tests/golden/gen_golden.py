@@ -21,6 +21,13 @@ Fixtures written (data only — inputs and expected outputs):
                           (total, recon, kld, mu, logvar, decoder_output) + all gradients; train-mode
                           with dropout=0 and the captured eps: same + gradients; and one train_batch
                           golden (params after one clip+Adam step, eval-mode gradients excluded)
+  golden_<cfg>.npz        round 3, slim, fresh-seed parameters, for the token counts at the edges of the supported range
+                          (include/dvs.h: n_tokens <= 48): n13c5 (N = 16: a full tile, no padding row), n14c14 (N = 17:
+                          first two-tile shape), n29c7 (N = 32: two full tiles), n45c45 (N = 48: three full tiles, 48 classes)
+  golden_train15_<cfg>.npz  round 3: the reference in TRAIN mode with dropout 0.15 under torch.manual_seed(seed) — losses +
+                          all 108 gradients; the oracle drawing from torch's generator in the same order must land on
+                          them, which pins the oracle's 34 dropout sites (order, shapes) and its eps draw
+                          (pace.py:45-67,135-154,201-221,1649-1664)
 """
 import os
 import sys
@@ -196,6 +203,57 @@ def main():
     golden(PaceVaeV3, "n37c37", 37, 37, None, alarm_graphs(), seed=10, slim=True)
     bn_data()
     predictor_data()
+    main_round3(PaceVaeV3, sd_asia)
+
+
+def edge_shape_graphs(n, card, count, seed):
+    """Graphs for the edge-of-range shapes: the synthetic curriculum plus a full path (deepest topological order) and a
+    star; labels uniform in [0, card) when card < n (the reference's label_random_method='choice' case)."""
+    graphs = ofeat.synthetic_dags(n, card, count - 2, seed=seed, density_limit=0.3 if n <= 16 else 0.2)
+    rng = np.random.default_rng(seed + 100)
+
+    def labels():
+        return [int(x) for x in (rng.permutation(card)[:n] if card >= n else rng.integers(0, card, n))]
+    graphs = [(labels(), e) for _, e in graphs]
+    graphs.append((labels(), [(v, v + 1) for v in range(n - 1)]))
+    graphs.append((labels(), [(0, v) for v in range(1, n)]))
+    return graphs
+
+
+def golden_train15(PaceVaeV3, name, n, card, sd, graphs, seed):
+    """Reference in train mode, dropout 0.15, torch's global generator seeded right before loss_direct."""
+    f = ofeat.to_torch(ofeat.dense_features(graphs, card))
+    model = build_model(PaceVaeV3, n, card, dropout=0.15)
+    model.load_state_dict(sd)
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(seed)
+    total, recon, kld = model.loss_direct(f)
+    total.backward()
+    out = {"seed": np.int64(seed), "num_graphs": np.int64(len(graphs)),
+           "total": np.float64(total.item()), "recon": np.float64(recon.item()), "kld": np.float64(kld.item())}
+    for k, g in grads_of(model).items():
+        out["grad/" + k] = g
+    np.savez_compressed(os.path.join(HERE, f"golden_train15_{name}.npz"), **out)
+    print(f"golden_train15_{name}: B={len(graphs)} seed={seed} total={out['total']:.6f} recon={out['recon']:.6f} kld={out['kld']:.6f}")
+
+
+def main_round3(PaceVaeV3=None, sd_asia=None):
+    """Round-3 additions only (``python tests/golden/gen_golden.py --round3``): leaves the earlier fixtures untouched."""
+    if PaceVaeV3 is None:
+        PaceVaeV3 = import_reference()
+    if sd_asia is None:
+        sd_asia = torch.load(f"{REF}/experiments/01_bn_asia/model_full_vectorized/model_checkpoint_110.pth",
+                             weights_only=True, map_location="cpu")
+    golden(PaceVaeV3, "n13c5", 13, 5, None, edge_shape_graphs(13, 5, 12, seed=21), seed=21, slim=True)
+    golden(PaceVaeV3, "n14c14", 14, 14, None, edge_shape_graphs(14, 14, 12, seed=22), seed=22, slim=True)
+    golden(PaceVaeV3, "n29c7", 29, 7, None, edge_shape_graphs(29, 7, 12, seed=23), seed=23, slim=True)
+    golden(PaceVaeV3, "n45c45", 45, 45, None, edge_shape_graphs(45, 45, 12, seed=24), seed=24, slim=True)
+    # dropout-site pin: same graphs / parameters as the existing goldens of these two configurations
+    z = np.load(os.path.join(HERE, "golden_n12c12.npz"))
+    sd12 = {k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
+    golden_train15(PaceVaeV3, "n12c12", 12, 12, sd12, ofeat.synthetic_dags(12, 12, 48, seed=12), seed=1234)
+    golden_train15(PaceVaeV3, "asia_rand", 8, 8, sd_asia, ofeat.synthetic_dags(8, 8, 48, seed=10), seed=4321)
 
 
 def bn_data():
@@ -253,4 +311,7 @@ def alarm_graphs():
 
 
 if __name__ == "__main__":
-    main()
+    if "--round3" in sys.argv:
+        main_round3()
+    else:
+        main()

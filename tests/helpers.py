@@ -15,7 +15,15 @@ CONFIGS = {
     "n12c1": dict(n=12, card=1, ckpt="n12c1_ckpt78.npz"),
     "n12c12": dict(n=12, card=12, ckpt=None),
     "n37c37": dict(n=37, card=37, ckpt=None),      # alarm-size (BASELINE config 5); slim fixture: no train-mode grads
+    # edges of the supported token range (include/dvs.h: n_tokens <= 48; pace.py:1159-1160,1188-1191), slim fixtures
+    "n13c5": dict(n=13, card=5, ckpt=None),        # N = 16: one FULL tile (no padding row), card != n
+    "n14c14": dict(n=14, card=14, ckpt=None),      # N = 17: first two-tile shape, one valid row in the last tile
+    "n29c7": dict(n=29, card=7, ckpt=None),        # N = 32: two full tiles, card != n
+    "n45c45": dict(n=45, card=45, ckpt=None),      # N = 48 tokens, C = 48 classes: the maximum of both
 }
+
+# configurations whose shapes were added in round 3 (VERDICT r2 "Missing 2")
+EDGE_SHAPES = ["n13c5", "n14c14", "n29c7", "n45c45"]
 
 
 def load_npz(name):

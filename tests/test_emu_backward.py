@@ -26,8 +26,12 @@ def _check_grads(got, ref, tol):
         assert err < tol, (k, err)
 
 
-@pytest.mark.parametrize("name,B", [("n12c12", 5), ("asia_rand", 6), ("n12c1", 3), ("n37c37", -4)])
+@pytest.mark.parametrize("name,B", [("n12c12", 5), ("asia_rand", 6), ("n12c1", 3), ("n37c37", -4),
+                                    ("n13c5", -3), ("n14c14", -3), ("n29c7", -3), ("n45c45", -3)])
 def test_emu_gradients_eval(name, B):
+    """Eval-mode gradients against the oracle on a slice of the fixture's graphs (the reference's own gradients of the
+    full fixtures are checked on the GPU and by tests/test_oracle.py); negative B = the LAST graphs of the fixture (the
+    path / star DAGs of the alarm-size and edge-shape fixtures)."""
     cfg, params, graphs, z = load_golden(name)
     graphs = graphs[:B] if B > 0 else graphs[B:]
     B = len(graphs)
@@ -133,11 +137,12 @@ def test_emu_batch_sharding_is_additive():
 
 
 @pytest.mark.parametrize("n,card,B,train", [(1, 1, 3, False), (2, 5, 2, True), (13, 13, 3, True), (14, 14, 2, True),
-                                            (13, 14, 2, False), (20, 3, 2, True), (45, 45, 2, False)])
+                                            (13, 14, 2, False), (20, 3, 2, True), (29, 7, 2, True), (45, 45, 2, False),
+                                            (45, 20, 2, True)])
 def test_emu_edge_sizes_forward_and_gradients(n, card, B, train):
     """Size edges of the path: the smallest graph (N = 4 tokens), the one-tile limit (N = 16), the smallest tiled shape
-    (N = 17), a shape that is wide only by its class count (C = 17), two tiles with few classes, and the maximum
-    (N = C = 48) — loss and all 108 gradients against the oracle (fresh-seed parameters), dropout on where marked."""
+    (N = 17), a shape that is wide only by its class count (C = 17), two tiles with few classes, two FULL tiles (N = 32),
+    and the maximum (N = C = 48; N = 48 with dropout on) — loss and all 108 gradients against the oracle (fresh-seed parameters), dropout on where marked."""
     cfg = po.PaceConfig(n=n, card=card)
     params = po.init_params(cfg, seed=5)
     graphs = ofeat.synthetic_dags(n, card, B, seed=3, density_limit=0.2 if n > 20 else 0.4)

@@ -6,7 +6,7 @@ import torch
 from oracle import features as ofeat
 from oracle import pace_oracle as po
 from oracle.rng import DeviceMasks
-from tests.helpers import CONFIGS, grad_err, graphs_from, load_golden, load_npz, rel
+from tests.helpers import CONFIGS, EDGE_SHAPES, grad_err, graphs_from, load_golden, load_npz, rel
 from tests.relu_trace import grad_errors, oracle_on_device_piece, record
 
 # Gradient bound of the deterministic parity tests, as a fraction of the tensor maximum (the old 2e-3 was 50x
@@ -141,6 +141,49 @@ def test_train_mode_dropout_on_matches_oracle_with_device_masks(name, B, seed):
     cfg, params, graphs, z = load_golden(name)
     model = build_model(cfg, params, dropout=0.15)
     dropout_on_parity(f"dropout_on[{name},B={B},seed={seed}]", model, params, cfg, graphs[:B], seed, 5)
+
+
+@pytest.mark.parametrize("name", EDGE_SHAPES)
+def test_edge_of_range_shapes_dropout_on_and_compact_front_end(name):
+    """Edges of the token range include/dvs.h promises (N = 16: full tile; 17: one valid row in the second tile; 32: two
+    full tiles; 48: maximum, with 48 classes), two of them with card != n (pace.py:1159-1160,1188-1191,1921-1970).  The
+    eval-mode ELBO and all 108 gradients of these fixtures against the REFERENCE's outputs run through the CONFIGS
+    parametrisation above; here: train mode with dropout on against the oracle under the device's masks, the device-side
+    front-end against the dense one, bitwise determinism and shard additivity at a batch that is not a multiple of the
+    workgroup's DAG count."""
+    from dags_vae_search_amd import encode_graphs
+    from dags_vae_search_amd.dist import shard_features
+    cfg, params, graphs, z = load_golden(name)
+    model = build_model(cfg, params, dropout=0.15)
+    dropout_on_parity(f"dropout_on[{name},B={len(graphs)},seed=13]", model, params, cfg, graphs, 13, 3)
+    model.eval()
+    f = feats_for(model, graphs)
+    cb = encode_graphs(graphs, cfg.n).to(DEV)
+    assert [x.item() for x in model.loss_direct(cb)] == [x.item() for x in model.loss_direct(f)]
+    # 77 DAGs (odd, > one workgroup's share): determinism + shard additivity with dropout on
+    from dags_vae_search_amd import LabeledGraph
+    from dags_vae_search_amd.synthetic import synthetic_dags
+    rng = np.random.default_rng(5)
+    many = [LabeledGraph([int(x) for x in (g.labels if cfg.card >= cfg.n else rng.integers(0, cfg.card, cfg.n))], g.edges)
+            for g in synthetic_dags(cfg.n, max(cfg.card, cfg.n), 77, seed=5, density_limit=0.2)]
+    model.train()
+    fm = model.prepare_features(many)
+    model.seed(2)
+    l1 = model.loss_and_grad(fm).clone()
+    g1 = model.flat_grads.clone()
+    model.seed(2)
+    l2 = model.loss_and_grad(fm).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, model.flat_grads)
+    tot, lsum = torch.zeros_like(g1), 0.0
+    for rank in range(2):
+        shard, off = shard_features(fm, rank, 2)
+        model.seed(2)
+        model.dag_offset = off
+        lsum += model.loss_and_grad(shard)[0].item()
+        tot += model.flat_grads
+    model.dag_offset = 0
+    assert rel(lsum, l1[0].item()) < 1e-5
+    assert (tot - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
 
 
 def test_encode_direct_known_answer():

@@ -100,6 +100,27 @@ def test_oracle_matches_reference_train0_and_step(name):
     assert worst_big < 1e-6 and worst_all < 3e-5
 
 
+@pytest.mark.parametrize("name", ["n12c12", "asia_rand"])
+def test_oracle_dropout_sites_match_reference_train_mode(name):
+    """Pins the ORDER and SHAPES of the oracle's 34 dropout sites and its eps draw: the reference ran in train mode with
+    dropout 0.15 under torch.manual_seed(seed) (tests/golden/gen_golden.py::golden_train15; pace.py:45-67,135-154,201-221,
+    1649-1664); the oracle, drawing from torch's generator (masks=None, eps=None), must consume the stream identically.
+    A site out of order or drawn on a differently shaped tensor moves the loss by O(1), not by rounding."""
+    cfg, params, graphs, _ = load_golden(name)
+    z = load_npz(f"golden_train15_{name}.npz")
+    assert int(z["num_graphs"]) == len(graphs)
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = ofeat.to_torch(ofeat.dense_features(graphs, cfg.card))
+    torch.manual_seed(int(z["seed"]))
+    total, recon, kld = po.loss_direct(P, cfg, f, training=True)
+    assert rel(total, z["total"]) < 1e-6
+    assert rel(recon, z["recon"]) < 1e-6
+    assert rel(kld, z["kld"]) < 1e-6
+    total.backward()
+    err, worst = grad_err({k: v.grad for k, v in P.items()}, z, "grad/")
+    assert err < 1e-5, (worst, err)
+
+
 def test_synthetic_dags_are_valid():
     gs = ofeat.synthetic_dags(12, 12, 64, seed=3)
     assert len(gs) == 64

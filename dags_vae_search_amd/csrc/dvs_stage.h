@@ -82,6 +82,10 @@ DVS_HD inline void dvs_plan_seg(DvsStagePlan& p, const char* smem, const void* l
 DVS_HD inline void dvs_plan_vec(DvsStagePlan& p, const char* smem, const float* lds_dst, const float* src, int n,
                                 bool perm = false) {
     for (int base = 0; base < n; base += 64) {
+        if (p.nvec >= DVS_PLAN_VECS) {     // host-side builder only: a plan that does not fit is a programming error of the
+            p.nvec = DVS_PLAN_VECS + 1;    // launcher; it is reported (dvs_plan_ok -> code 20), never written past the arrays
+            return;
+        }
         p.vsrc[p.nvec] = src;
         p.vdst[p.nvec] = (int)(((const char*)lds_dst - smem) >> 2);
         p.vbase[p.nvec] = base;
@@ -120,7 +124,15 @@ typedef const DvsStagePlan* DvsPlanK;
 // under a runtime condition makes hipcc branch around it and wait for it (vmcnt(0)) before the next one — 9-14 dependent
 // L2 round trips per phase instead of one batch in flight (measured: the first version of this file, with `if (k < total)
 // v = *src`, made the chained kernels 10-20 % SLOWER than staging behind the barrier).  Only the LDS stores are predicated.
+DVS_HD inline bool dvs_plan_ok(const DvsStagePlan& p) { return p.nvec <= DVS_PLAN_VECS; }
+void dvs_note_hip_error(const char* what, int hip_error, const char* hip_message);       // dvs_api.hip: the call returns code 20
 DVS_HD inline void dvs_plan_seal(DvsStagePlan& p) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (!dvs_plan_ok(p)) {          // dvs_plan_vec refused a unit: surface it as a failed launch instead of staging a partial plan
+        dvs_note_hip_error("staging plan", -1, "more than DVS_PLAN_VECS vector units (launcher bug)");
+        p.nvec = DVS_PLAN_VECS;
+    }
+#endif
     for (int i = 0; i < DVS_PLAN_VECS; ++i)
         if (i >= p.nvec || !p.vsrc[i] || p.vlen[i] <= 0) {
             p.vsrc[i] = (const float*)p.src;

@@ -260,7 +260,8 @@ class PaceVaeV3(nn.Module):
             self._grads_and_losses = torch.zeros(P + 8, dtype=torch.float32, device=self.flat_params.device)
             self.flat_grads = self._grads_and_losses[:P]
             self._step_losses = self._grads_and_losses[P:P + dl.LOSS_FLOATS]
-            self._step_guard = self._grads_and_losses[P + 3:P + 5]      # dvs_clip_adam skips the update when either is set
+            self._fixed_guard = self._grads_and_losses[P + 3:P + 5]     # dvs_clip_adam skips the update when either is set
+            self._step_guard = self._fixed_guard                        # (the notify variant of a step re-points it, loss_and_grad)
             self._step_tail = self._grads_and_losses[P:P + 8]
             self._step_status = self._grads_and_losses[P + 7:P + 8].view(torch.int32)
             self._host_tail = torch.zeros(8, dtype=torch.float32)
@@ -320,14 +321,14 @@ class PaceVaeV3(nn.Module):
         eng.pack(f, check=check, zero_status=zero_status)
         return f["vertex_label_features"].shape[0]
 
-    def _early_read(self, group=None, reduce_group=None):
+    def _early_read(self, exchange=None):
         """Called between the forward and the backward of a fused step: the [losses, flags | validation word] tail is final
         once the forward has run, so its device->host copy (and the re-arming of the validation word) goes to a side stream
         behind an event.  The host then blocks only until the FORWARD is done — where the reference's ``loss.item()``
         blocks (main.py:104) — and enqueues the next step while this step's backward and optimiser are still running.
-        Data-parallel (``group`` true): the five scalars are SUM-all-reduced on the side stream first (a 20-byte
-        collective that overlaps the backward), so the host reads GLOBAL losses / flags just as early, and the optimiser's
-        guard (``_dp_guard``) sees the flags of every rank."""
+        Data-parallel (``exchange``: a ``dist.DpExchange``): the five scalars are SUM-all-reduced on the side stream first
+        (``exchange.scalars``: an 8-float collective that overlaps the backward), so the host reads GLOBAL losses / flags just
+        as early, and the optimiser's guard (``exchange.guard``) sees the flags of every rank."""
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.flat_params.device)
             self._ev_forward = torch.cuda.Event()
@@ -336,14 +337,8 @@ class PaceVaeV3(nn.Module):
         with torch.cuda.stream(self._side_stream):
             self._side_stream.wait_event(self._ev_forward)
             src = self._step_losses
-            if group:
-                import torch.distributed as dist
-                if getattr(self, "_global_scalars", None) is None or self._global_scalars.device != src.device:
-                    self._global_scalars = torch.zeros(8, dtype=torch.float32, device=src.device)
-                    self._dp_guard = self._global_scalars[3:5]
-                self._global_scalars[:dl.LOSS_FLOATS].copy_(src)
-                dist.all_reduce(self._global_scalars, op=dist.ReduceOp.SUM, group=reduce_group)
-                src = self._global_scalars[:dl.LOSS_FLOATS]
+            if exchange is not None:
+                src = exchange.scalars(src)
                 self._host_tail[:dl.LOSS_FLOATS].copy_(src, non_blocking=True)
                 self._host_tail[7:8].copy_(self._step_tail[7:8], non_blocking=True)
             else:
@@ -365,13 +360,23 @@ class PaceVaeV3(nn.Module):
             seq, spins = self._host_seq, 0
             while int(words[3]) >> 8 != seq:                        # the device's ONE 16-byte store carries the sequence number
                 spins += 1
-                if spins > 2_000_000:                               # ~seconds: the forward never takes that long; fail loudly
+                if spins > 2_000_000:                               # ~0.3-0.5 s of polling: then fall back to a stream synchronise
                     torch.cuda.current_stream().synchronize()
                     if int(words[3]) >> 8 != seq:
                         raise RuntimeError("the device never signalled the end of the forward (dvs_loss_forward_notify)")
-            word = int(words[3])
-            vals = self._host_tail[:3].tolist() + [float((word >> 6) & 1), float((word >> 7) & 1)]
-            self._early_scalars = torch.tensor(vals)                # the caller's recon / kld (host tensors on this path)
+            # ONE 16-byte store on the device side, but the host reads four separate words: take the payload, then check that
+            # the sequence word still says the same (include/dvs.h states the coherence requirement on this buffer; nothing
+            # else writes it before the NEXT step's forward, which this thread has not enqueued yet — the re-read is the cheap
+            # proof that payload and sequence number belong together)
+            for _ in range(4):
+                word = int(words[3])
+                vals = self._host_tail[:3].tolist() + [float((word >> 6) & 1), float((word >> 7) & 1)]
+                if int(words[3]) == word and word >> 8 == seq:
+                    break
+            else:
+                raise RuntimeError("dvs_loss_forward_notify: the notification packet kept changing while it was read")
+            # the caller's recon / kld: 0-d views of THIS step's own device tensor (main.py:111-118 returns device tensors)
+            self._early_scalars = self._notify_losses
             return vals, word & 0x3F
         if self._early_pending:
             self._early_pending = False
@@ -478,8 +483,8 @@ class PaceVaeV3(nn.Module):
 
     # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
-                      packed: bool = False, defer_check: bool = False, early_read: bool = False, group=None,
-                      reduce_group=None) -> torch.Tensor:
+                      packed: bool = False, defer_check: bool = False, early_read: bool = False,
+                      exchange=None) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag, invalid-features flag]; nothing is synchronised."""
         eng = self._eng()
@@ -496,19 +501,27 @@ class PaceVaeV3(nn.Module):
         shape = self._shape(B, beta)
         grads = self.flat_grads
         losses = self._step_losses            # tail of the gradient allocation (see bind_flat_grads); rewritten each step
+        self._step_guard = self._fixed_guard
         # early read, one GPU: the kernel that reduces the losses writes the scalars, the validation word and — last — this step's
         # sequence number into pinned host memory (dvs_loss_forward_notify); read_step() polls for it.  No event and no copy on
         # any stream: an event recorded between the forward and the backward cost the main stream ~12 us per step.
-        notify = early_read and not group and self._host_tail.is_pinned() and _EARLY_READ_MODE != "event"
+        # Data-parallel steps (``exchange``) always take the event + side-stream variant — their scalars pass through the
+        # all-reduce first — whatever DVS_EARLY_READ says, so every rank issues the same collectives.
+        notify = early_read and exchange is None and self._host_tail.is_pinned() and _EARLY_READ_MODE != "event"
         if notify:
             self._host_seq = (getattr(self, "_host_seq", 0) + 1) & 0xFFFFFF or 1
+            # this step's scalars get a device tensor of their own: train_batch hands 0-d views of it to the caller (the
+            # reference returns device tensors, main.py:111-118), and the next step must not overwrite them (caching allocator:
+            # a host-side free-list pop, no device work)
+            losses = self._notify_losses = torch.empty(8, dtype=torch.float32, device=grads.device)[:dl.LOSS_FLOATS]
+            self._step_guard = losses[3:5]
             eng.loss_forward(shape, self.flat_params, eps, losses, host_tail=self._host_tail, host_seq=self._host_seq)
             self._early_pending = "poll"
         else:
             eng.loss_forward(shape, self.flat_params, eps, losses)
         self._fwd_generation += 1
         if early_read and not notify:
-            self._early_read(group, reduce_group)
+            self._early_read(exchange)
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta

@@ -25,8 +25,9 @@ def _as_compact(model, graphs) -> CompactBatch:
 
 def generate_predictor_graphs_batch(model, evaluator, graphs) -> Tuple[torch.Tensor, torch.Tensor]:
     """src/predictors/utils.py:15-34 for a whole batch: (vectors float32 [B, latent], targets float64 [B]), both on the
-    model's device.  ``evaluator``: a ``bic.BNLearnWrapper`` (its ``score_compact``), or any callable graph -> float (the
-    reference's signature; then the targets come from that callable, one graph at a time, on the host)."""
+    model's device.  ``evaluator``: a ``bic.BNLearnWrapper`` or — the reference's call shape, experiments/01_bn_asia/
+    main.py:296 — its bound ``.score`` method (both take the batched on-device path through ``score_compact``), or any other
+    callable graph -> float (then the targets come from that callable, one graph at a time, on the host)."""
     dev = model.flat_params.device
     batch = _as_compact(model, graphs).to(dev)
     was_training = model.training
@@ -35,8 +36,9 @@ def generate_predictor_graphs_batch(model, evaluator, graphs) -> Tuple[torch.Ten
         mu, _ = model.encode_direct(batch)
     finally:
         model.train(was_training)
-    if hasattr(evaluator, "score_compact"):
-        y = evaluator.score_compact(batch)
+    owner = getattr(evaluator, "__self__", evaluator)      # `BNLearnWrapper(...).score` (a bound method) -> the wrapper
+    if getattr(evaluator, "__name__", "score") == "score" and hasattr(owner, "score_compact"):
+        y = owner.score_compact(batch)
     else:
         from .records import decode_graphs
         y = torch.tensor([float(evaluator(g)) for g in decode_graphs(batch)], dtype=torch.float64, device=dev)
@@ -46,7 +48,9 @@ def generate_predictor_graphs_batch(model, evaluator, graphs) -> Tuple[torch.Ten
 def create_predictor_dataset(model, graphs_dataloader: Iterable, output_dir: Optional[str], evaluator,
                              npartitions: int = 4):
     """src/predictors/utils.py:37-59: one ``part-{i}.parquet`` per batch of the loader under ``output_dir`` (columns
-    ``vector``, ``target``).  With ``output_dir=None`` nothing is written.  Returns (vectors [N, latent], targets [N]) on the
+    ``vector``, ``target``).  Difference on purpose: the reference writes its parts into ``output_dir + '_tmp'``
+    (utils.py:45) and leaves the re-partitioning into ``output_dir`` commented out; here the parts go to ``output_dir``
+    itself, which is where its readers (main.py:315-330) look.  With ``output_dir=None`` nothing is written.  Returns (vectors [N, latent], targets [N]) on the
     device, rows in loader order.  ``npartitions`` is accepted for signature compatibility (the reference ignores it too)."""
     vecs: List[torch.Tensor] = []
     tgts: List[torch.Tensor] = []

@@ -52,29 +52,34 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
         # are all-reduced there too (a 20-byte collective overlapping the backward), the flat gradient is all-reduced on the
         # main stream after the backward (ONE collective of P floats, SUM, then clip: SURVEY 8e).
         dp = group is not None
-        pg = None if group is True else group
-        model.loss_and_grad(batch, defer_check=True, early_read=True, group=dp, reduce_group=pg)
+        ex = None
+        if dp:
+            from .dist import DpExchange
+            pg = None if group is True else group
+            ex = getattr(model, "_dp_exchange", None)
+            if ex is None or ex.group is not pg:
+                ex = model._dp_exchange = DpExchange(pg)
+        # forward -> [side stream: ex.scalars] -> backward   (dist.DpExchange documents the order of the two collectives)
+        model.loss_and_grad(batch, defer_check=True, early_read=True, exchange=ex)
         guard = model._step_guard
         if dp:
-            import torch.distributed as dist
-            dist.all_reduce(model.flat_grads, op=dist.ReduceOp.SUM, group=pg)
+            ex.gradient(model.flat_grads)
             torch.cuda.current_stream().wait_event(model._ev_tail)     # the guard below reads the all-reduced flags
-            guard = model._dp_guard
+            guard = ex.guard
         # A non-finite loss or an invalid batch must leave the weights and the moments alone: the reference raises inside
         # loss_direct (pace.py:97-98), before backward / clip / step (main.py:111-116).  The optimiser kernels are already
         # enqueued when the host learns about it, so they carry the two flags as a device-side guard and skip the update
         # (data-parallel: the flags were all-reduced with the losses, every rank skips and raises alike).
         optimizer.step(max_grad_norm=max_grad_norm, guard=guard)
-        host, status = model.read_step()                            # waits for the side stream's copy only
-        scalars = model._early_scalars                              # cloned behind the forward on the side stream
+        host, status = model.read_step()                            # waits for the forward's notification / the side stream's copy only
+        scalars = model._early_scalars                              # 0-d views of a device tensor owned by this step
         recon, kld = scalars[1], scalars[2]
-        if status != 0 or host[4] != 0.0:
+        try:
+            from .dist import DpExchange as _Dp
+            _Dp.decide(host, status)
+        except ValueError:
             optimizer.step_skipped()
-            raise ValueError(f"batch violates the feature invariants (status bits {status:#x}"
-                             f"{'' if status else ', raised on another rank'})")
-        if host[3] != 0.0:
-            optimizer.step_skipped()
-            raise ValueError("NaN detected in the output of the PACE-VAE step")    # pace.py:97-98
+            raise
         return host[0], recon, kld
     loss, recon, kld = model.loss_direct(batch)
     loss_value = loss.item()

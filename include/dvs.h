@@ -112,7 +112,13 @@ int dvs_loss_forward(const dvs_shape* s, const void* records, size_t records_byt
  * = (host_seq << 8) | (invalid-features flag << 7) | (non-finite flag << 6) | (validation word *status & 0x3F).  A host that
  * polls word [3] until its upper 24 bits equal the host_seq it passed (24 bits are kept), and reads [0..2] AFTER that, has final
  * values where the reference's `loss.item()` returns (experiments/03_synthetic_12/main.py:104), while backward and optimiser
- * are still queued.  With host_tail the validation word is RE-ARMED (*status = 0) once it has been read: status is written. */
+ * are still queued.  With host_tail the validation word is RE-ARMED (*status = 0) once it has been read: status is written.
+ * Coherence REQUIREMENT on host_tail (the library cannot check it): fine-grained / coherent pinned memory — what
+ * hipHostMalloc gives by default (hipHostMallocCoherent) and what torch.pin_memory() allocates —, uncached on the device, so
+ * that the single 16-byte store becomes one PCIe write the host sees whole; memory registered non-coherent
+ * (hipHostMallocNonCoherent, hipExtHostRegisterCoarseGrained) is only guaranteed visible at the end of the kernel and must
+ * not be used.  A careful host re-reads word [3] AFTER reading [0..2] and retries when it changed (the Python driver does);
+ * a host that cannot rely on this passes host_tail = NULL and waits for an event instead (DVS_EARLY_READ=event). */
 int dvs_loss_forward_notify(const dvs_shape* s, const void* records, size_t records_bytes, const float* params,
                             int64_t n_params, void* workspace, size_t workspace_bytes, const float* eps, int32_t* status,
                             float* losses, float* mu, float* logvar, void* host_tail, uint32_t host_seq, void* stream);

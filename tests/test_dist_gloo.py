@@ -1,6 +1,8 @@
-"""N>1 path on CPU (gloo, world_size 2): sharding + the single SUM all-reduce + clip-after-reduce + replicated Adam
-reproduce the single-process big-batch step.  The per-rank gradient here comes from the ORACLE (tests may use it);
-on GPUs the same dist.shard_features / dist.allreduce_gradients wrap the HIP kernels (train.train_batch(group=...))."""
+"""N>1 path on CPU (gloo, world_size 2): sharding + the step's two SUM all-reduces (five scalars behind the forward,
+flat gradient behind the backward) + guarded clip-after-reduce + replicated Adam reproduce the single-process big-batch
+step, and a flag raised on one rank skips the update on all of them.  The exchange runs through dist.DpExchange — the
+object train.train_batch(group=...) itself drives on GPUs over RCCL —; only the per-rank forward / backward come from the
+ORACLE here (tests may use it)."""
 import os
 import socket
 
@@ -20,6 +22,41 @@ def _flat(grads, names):
     return torch.cat([grads[n].reshape(-1) for n in names])
 
 
+def _rank_step(rank, world, params, names, feats, eps_all, ex, poison_rank=None):
+    """One data-parallel train step of one rank with the PRODUCT's exchange object (dist.DpExchange) in the product's order
+    (train.train_batch): forward -> ex.scalars -> backward -> ex.gradient -> guarded clip + Adam -> ex.decide.  The local
+    forward / backward come from the oracle (CPU); `poison_rank` raises the invalid-features flag on that rank only."""
+    cfg = po.PaceConfig(n=8, card=8, dropout=0.0)
+    B = feats["vertex_label_features"].shape[0]
+    shard, off = ddist.shard_features(feats, rank, world)
+    lo, hi = ddist.shard_bounds(B, rank, world)
+    assert off == lo and shard["vertex_label_features"].shape[0] == hi - lo
+    assert shard["target_masks"].shape[0] == 8 * (hi - lo) and len(shard["vertex_labels"]) == hi - lo
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    total, recon, kld = po.loss_direct(P, cfg, shard, training=True, eps=eps_all[lo:hi])
+    # 1. right behind the forward: the five scalars (+ 3 padding words) through the first collective
+    mine = torch.tensor([float(total), float(recon), float(kld), 0.0, float(rank == poison_rank)])
+    five = ex.scalars(mine).clone()
+    guard = ex.guard.clone()
+    # 2. behind the backward: the flat gradient through the second collective
+    total.backward()
+    flat = ex.gradient(_flat({k: v.grad for k, v in P.items()}, names).clone())
+    # guarded clip (AFTER the reduce) + replicated Adam: dvs_clip_adam skips the update on the device when a flag is set
+    flat_p = _flat(params, names).clone().requires_grad_(True)
+    if not bool(guard.any()):
+        coef = min(1.0, 1.0 / (float(flat.norm()) + 1e-6))
+        opt = torch.optim.Adam([flat_p], lr=1e-4)
+        flat_p.grad = flat * coef
+        opt.step()
+    # 3. the host's decision from the REDUCED flags (this rank's own status word: set only where the batch was bad)
+    raised = None
+    try:
+        ddist.DpExchange.decide(five.tolist(), status=1 if rank == poison_rank else 0)
+    except ValueError as e:
+        raised = str(e)
+    return five.numpy().copy(), flat.numpy().copy(), flat_p.detach().numpy().copy(), raised
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,43 +64,27 @@ def _worker(rank, world, port, out):
     cfg = po.PaceConfig(n=8, card=8, dropout=0.0)
     params = po.init_params(cfg, seed=1)
     names = list(params)
-    graphs = synthetic_dags(8, 8, 10, seed=5)
-    feats = prepare_features(graphs, 11, 11)
+    feats = prepare_features(synthetic_dags(8, 8, 10, seed=5), 11, 11)
     eps_all = torch.randn(10, 32, generator=torch.Generator().manual_seed(3)) * 0.01
-    shard, off = ddist.shard_features(feats, rank, world)
-    lo, hi = ddist.shard_bounds(10, rank, world)
-    assert off == lo and shard["vertex_label_features"].shape[0] == hi - lo
-    assert shard["target_masks"].shape[0] == 8 * (hi - lo) and len(shard["vertex_labels"]) == hi - lo
-    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    total, recon, kld = po.loss_direct(P, cfg, shard, training=True, eps=eps_all[lo:hi])
-    total.backward()
-    g = _flat({k: v.grad for k, v in P.items()}, names)
-    # the product's layout (PaceVaeV3.bind_flat_grads): the 5 step scalars [total, recon, kld, non-finite flag,
-    # invalid-features flag] sit right behind the gradient in ONE allocation (followed by 3 rank-local words that must NOT
-    # travel), so allreduce_gradients sends both in a single collective; rank 1 builds the same message by hand.  Rank 1 raises the invalid-features flag: every rank must see it afterwards (they
-    # all skip the update and raise, train.train_batch).
-    mine = [float(total), float(recon), float(kld), 0.0, float(rank == 1)]
+    ex = ddist.DpExchange(None)
+    clean = _rank_step(rank, world, params, names, feats, eps_all, ex)
+    # second step on the same exchange object: rank 1's batch is invalid -> BOTH ranks must skip the update and raise
+    bad = _rank_step(rank, world, params, names, feats, eps_all, ex, poison_rank=1)
+    # the legacy single-collective form (dist.allreduce_gradients: gradient + scalars in one message) still pairs with a
+    # hand-built message of the same shape, and leaves the 3 rank-local tail words alone
+    g = torch.from_numpy(clean[1]).clone()
     if rank == 0:
         both = torch.zeros(g.numel() + 8)
         flat, losses = both[:g.numel()], both[g.numel():g.numel() + 5]
         flat.copy_(g)
-        losses.copy_(torch.tensor(mine))
-        both[-1] = 123.0                          # rank-local status word
+        both[-1] = 123.0
         ddist.allreduce_gradients(flat, losses)
         assert both[-1] == 123.0 and both[-2] == 0.0 and both[-3] == 0.0
     else:
-        both = torch.cat([g, torch.tensor(mine)])        # same collective shape as rank 0's single call
+        both = torch.cat([g, torch.zeros(5)])
         dist.all_reduce(both)
-        flat, losses = both[:g.numel()], both[g.numel():]
-    assert losses[4] == 1.0 and losses[3] == 0.0
-    flat, losses = flat.clone(), losses.clone()
-    # clip AFTER the reduce, then replicated Adam
-    coef = min(1.0, 1.0 / (float(flat.norm()) + 1e-6))
-    flat_p = _flat(params, names).clone().requires_grad_(True)
-    opt = torch.optim.Adam([flat_p], lr=1e-4)
-    flat_p.grad = flat * coef
-    opt.step()
-    out[rank] = (losses.numpy().copy(), flat.numpy().copy(), flat_p.detach().numpy().copy())
+    assert torch.equal(both[:g.numel()], 2 * g)
+    out[rank] = (clean, bad)
     dist.destroy_process_group()
 
 
@@ -82,11 +103,20 @@ def test_two_rank_step_equals_single_process_step():
     tr = po.OracleTrainer(cfg, params)
     value, recon, kld = tr.step(feats, training=True, eps=eps_all)
     ref_p = _flat({k: v.detach() for k, v in tr.P.items()}, names).numpy()
-    l0, g0, p0 = out[0]
-    l1, g1, p1 = out[1]
+    (l0, g0, p0, r0), bad0 = out[0]
+    (l1, g1, p1, r1), bad1 = out[1]
+    assert r0 is None and r1 is None
     assert np.array_equal(g0, g1) and np.array_equal(p0, p1)          # ranks stay identical without a broadcast
+    assert np.array_equal(l0, l1) and l0[3] == 0.0 and l0[4] == 0.0
     assert abs(l0[0] - value) < 1e-4 * abs(value)
     assert np.abs(p0 - ref_p).max() < 2e-5
+    # the poisoned step: the flag raised on rank 1 is seen by both, nobody updates, everybody raises
+    start = _flat(params, names).numpy()
+    for (l, g, p, raised), rank in ((bad0, 0), (bad1, 1)):
+        assert l[4] == 1.0 and l[3] == 0.0
+        assert np.array_equal(p, start)
+        assert raised is not None and "feature invariants" in raised
+        assert ("raised on another rank" in raised) == (rank == 0)
 
 
 def test_shard_bounds_cover_batch():

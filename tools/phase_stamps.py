@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
     from dags_vae_search_amd import _lib as dl
-    dl.LIB_NAME = os.environ.get("DVS_STAMPS_LIB", "libdvs_hip_stamps.so")      # variant builds of the diagnostic library
+    dl.LIB_NAME = os.environ.get("DVS_STAMPS_LIB", os.path.join(REPO, "tools", "_diag", "libdvs_hip_stamps.so"))      # variant builds of the diagnostic library
     from dags_vae_search_amd import PaceVaeV3, optim as dopt, prepare_features
     from dags_vae_search_amd.synthetic import synthetic_dags
     from dags_vae_search_amd.train import train_batch

@@ -2,7 +2,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from dags_vae_search_amd import _lib as dl
-dl.LIB_NAME = "libdvs_hip_stamps.so"
+dl.LIB_NAME = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_diag", "libdvs_hip_stamps.so")   # absolute: outside the package
 from dags_vae_search_amd import PaceVaeV3, optim as dopt, prepare_features
 from dags_vae_search_amd.synthetic import synthetic_dags
 from dags_vae_search_amd.train import train_batch

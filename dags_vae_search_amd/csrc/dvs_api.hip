@@ -335,9 +335,30 @@ static int grid_for(int units, int per_wg = 8) {   // persistent forward kernels
     return want < cap ? want : cap;
 }
 
-int dvs_num_slabs() {   // backward kernels run on exactly this many workgroups (one gradient slab each)
+int dvs_num_slabs() {   // backward kernels run on at most this many workgroups (one gradient slab each); sizes the workspace
     const int cus = dvs_device_cus();
     return cus > 0 ? cus : 256;
+}
+
+// Waves per workgroup of the one-tile stack kernels (k_fwd_stack / k_bwd_stack and their per-phase twins).  8: two waves per
+// SIMD, 8 DAGs per workgroup and pass — the mapping every kernel was tuned for; it fills the chip from 8 x #CU DAGs up.  Below
+// 4 x #CU DAGs (1 024 on an MI355X: a 4 096 batch cut over 4 or 8 GPUs) half of the CUs or more would idle while the others
+// run two waves per SIMD, so the NARROW mapping takes over: 4 waves (one cooperative weight-gradient group), 4 DAGs per
+// workgroup, twice the workgroups, one wave per SIMD.  DVS_WAVES_PER_WG=4|8 forces either (A/B runs, tests).
+static int waves_per_wg(const DvsDims& d, bool wide) {
+    const char* env = getenv("DVS_WAVES_PER_WG");         // read per call: the tests switch it between calls
+    const int force = env ? atoi(env) : 0;
+    if (wide) return 8;
+    if (force == 4 || force == 8) return force;
+    return d.B <= 4 * dvs_num_slabs() ? 4 : 8;
+}
+// Workgroups of the backward kernels = gradient slabs that are written (and reduced) this step: all of them from 4 x #CU
+// DAGs up; fewer for smaller batches, so that k_reduce_slabs does not stream slabs of zeros.
+static int active_slabs(const DvsDims& d, bool wide) {
+    const int all = dvs_num_slabs();
+    if (wide) return all;
+    const int want = (d.B + 3) / 4;          // the narrowest backward kernels own 4 DAGs per workgroup and pass
+    return want < all ? want : all;
 }
 
 extern "C" int64_t dvs_param_count(const dvs_shape* s) {
@@ -515,6 +536,8 @@ static inline const void* wimg_ffn(const float* ws, const DvsWorkspace& W, int b
 // launch grids of the forward kernels
 struct FwdGrids {
     bool wide;
+    int nw;         // waves per workgroup of the one-tile stack kernels (waves_per_wg)
+    int chain;      // k_fwd_stack / k_attn_fwd / narrow k_ffn_fwd, k_embed_fwd, k_loss_fwd: nw tiles per workgroup and pass
     int tiles16;    // 16-wave tile-parallel kernels (k_ffn_fwd, one-tile k_embed_fwd)
     int attn;       // one-tile k_attn_fwd (DVS_ATTN_FWD_THREADS / 64 waves per workgroup)
     int tiles8;     // 8-wave tile-parallel kernels (one-tile k_attn_fwd / k_embed_fwd / k_loss_fwd)
@@ -524,6 +547,8 @@ struct FwdGrids {
 static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
     FwdGrids g;
     g.wide = wide;
+    g.nw = waves_per_wg(d, wide);
+    g.chain = grid_for(d.B * d.NT, g.nw);
     g.tiles16 = grid_for(d.B * d.NT, 16);
     g.attn = grid_for(d.B * d.NT, dvs_attn_fwd_waves());
     g.tiles8 = grid_for(d.B * d.NT, 8);
@@ -533,11 +558,13 @@ static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
 }
 static void launch_embed_fwd(const EmbedArgs& e, const FwdGrids& g, dvs_stream_t st) {
     if (g.wide) dvs_launch_embed_fwd_w(e, g.tiles4, st);
-    else dvs_launch_embed_fwd(e, g.tiles16, st);
+    else if (g.nw == 4) dvs_launch_embed_fwd(e, g.chain, 4, st);
+    else dvs_launch_embed_fwd(e, g.tiles16, 16, st);
 }
 static void launch_attn_fwd(const AttnArgs& a, const FwdGrids& g, dvs_stream_t st) {
     if (g.wide) dvs_launch_attn_fwd_w(a, g.dags, st);
-    else dvs_launch_attn_fwd(a, g.attn, st);
+    else if (g.nw == 4) dvs_launch_attn_fwd(a, g.chain, 4, st);
+    else dvs_launch_attn_fwd(a, g.attn, 8, st);
 }
 // One-tile path: the sublayers of the encoder / decoder are chained into one launch each (k_fwd_stack); the wide path and
 // DVS_SPLIT_STACK=1 (per-phase profiling) launch every sublayer on its own.
@@ -564,18 +591,20 @@ struct FwdChain {
     }
     void ffn(const FfnArgs& f) {
         if (chain) next(DVS_FPH_FFN).u.f = f;
-        else dvs_launch_ffn_fwd(f, g.tiles16, st);
+        else if (g.nw == 4 && !g.wide) dvs_launch_ffn_fwd(f, g.chain, 4, st);
+        else dvs_launch_ffn_fwd(f, g.tiles16, 16, st);
     }
     // the latent block as the last phase of the encoder chain (the workgroups of the chain own 16 DAGs each: one MFMA
     // group); false: not chained, the caller launches k_latent_fwd
     bool latent(const LatentArgs& l) {
         static const bool off = getenv("DVS_LATENT_KERNELS") && atoi(getenv("DVS_LATENT_KERNELS")) != 0;   // A/B: own launches
-        if (!chain || off || stack.nphase == 0 || stack.nphase == DVS_FWD_STACK_PHASES) return false;
+        // (narrow mapping: a workgroup owns 4 DAGs, a quarter of an MFMA column group: the latent block keeps its own launch)
+        if (!chain || off || g.nw != 8 || stack.nphase == 0 || stack.nphase == DVS_FWD_STACK_PHASES) return false;
         next(DVS_FPH_LATENT).u.l = l;
         return true;
     }
     void flush() {
-        if (stack.nphase > 0) dvs_launch_fwd_stack(stack, tag, g.tiles8, st);
+        if (stack.nphase > 0) dvs_launch_fwd_stack(stack, tag, g.chain, g.nw, st);
         stack.nphase = 0;
     }
 };
@@ -811,7 +840,8 @@ extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, 
     }
     decoder_forward(d, L, W, rec, params, ws, grid, dec_in, st);
     if (grid.wide) dvs_launch_loss_fwd_w(dvs_loss_args(d, L, W, rec, params, ws), grid.dags, st);
-    else dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.tiles8, st);
+    else if (grid.nw == 4) dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.chain, 4, st);
+    else dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.tiles8, 8, st);
     FinalizeArgs fa;
     fa.B = d.B;
     fa.beta = d.beta;

@@ -107,10 +107,11 @@ struct BwdStackArgs {
     LatentBwdArgs lat;
 };
 static_assert(sizeof(BwdStackArgs) <= 4096, "kernel argument block limit");
-void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 decoder, 1 encoder (profile names)
-void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st);
-void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st);
-void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st);
+// nw: waves per workgroup, 8 or 4 (dvs_api.hip: dvs_waves_per_wg); every launch of one step uses the same value
+void dvs_launch_bwd_stack(const BwdStackArgs& s, int tag, int grid, int nw, dvs_stream_t st);   // tag 0 decoder, 1 encoder (profile names)
+void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, int nw, dvs_stream_t st);
+void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, int nw, dvs_stream_t st);
+void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, int nw, dvs_stream_t st);
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st);
@@ -269,24 +270,30 @@ __device__ __forceinline__ float dvs_colsum(const float* slot, const Lane& L) {
 // Add the two groups' partial dW (rows 16*(wave&3).. each) and write the 64x64 result to the slab, in two halves around ONE
 // workgroup barrier shared by all matrices (and the vector sums) of a phase's epilogue: waves 0-3 stage every matrix in its
 // own 4096-float LDS buffer, barrier, waves 4-7 add theirs and store.  (Round 1 paid two barriers per matrix.)
+// NW = waves per workgroup: 8 (two groups, as described) or 4 (ONE group — the narrow mapping dvs_api.hip picks for small
+// batches, one DAG round on every CU instead of two waves per SIMD on half of them): then the group's accumulators ARE the
+// workgroup's partial and go straight to the slab.
+template <int NW = 8>
 __device__ __forceinline__ void dvs_coop_stage(float* buf, const f4 (&acc)[4], const Lane& L) {
-    if (L.wave >= 4) return;
+    if (NW == 4 || L.wave >= 4) return;
     const int ot = L.wave & 3;
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) buf[(16 * ot + 4 * L.g + reg) * 64 + 16 * it + L.r] = acc[it][reg];
 }
+template <int NW = 8>
 __device__ __forceinline__ void dvs_coop_flush(const float* buf, float* dst, const f4 (&acc)[4], const Lane& L, bool rperm = false,
                                                bool cperm = false, int ld_dst = 64) {
-    if (L.wave < 4) return;
+    if (NW == 8 && L.wave < 4) return;
     const int ot = L.wave & 3;
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = 16 * ot + 4 * L.g + reg, col = 16 * it + L.r;
-            dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = acc[it][reg] + buf[row * 64 + col];
+            const float v = NW == 8 ? acc[it][reg] + buf[row * 64 + col] : acc[it][reg];
+            dst[(size_t)(rperm ? dvs_pi(row) : row) * ld_dst + (cperm ? dvs_pi(col) : col)] = v;
         }
 }
 // LayerNorm backward without the parameter-gradient accumulation (done by column sums of parked tiles)

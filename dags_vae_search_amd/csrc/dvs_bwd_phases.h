@@ -1,7 +1,8 @@
 // The three phases of the transformer-stack backward — FFN sublayer, stacked-projection (q/k/v) backward with fused
 // LayerNorm backward, attention core — as device functions over one 512-thread workgroup and its dynamic LDS.
 // k_backward.hip wraps each in its own kernel (wide path, per-phase profiling) and chains them in k_bwd_stack: every
-// phase maps DAG `dvs_bid() * 8 + wave (+ gridDim.x * 8 ...)` to the same wave, so the tiles a phase reads were written
+// phase maps DAG `dvs_bid() * NW + wave (+ gridDim.x * NW ...)` to the same wave (NW = 8 waves per workgroup, or 4 in the
+// narrow mapping for small batches: dvs_api.hip, dvs_waves_per_wg), so the tiles a phase reads were written
 // by the same wave in the phase before and a workgroup barrier is the only synchronisation between phases.
 #pragma once
 #include "dvs_backward.h"
@@ -178,13 +179,13 @@ __device__ __forceinline__ void dvs_tail_commit(const DvsBwdTail& t, PP next, bo
 // mine / stage_mine: this phase's staging plan; stage_mine is false when the previous phase of the chain already put it into
 // LDS (and a barrier has passed since).  next / has_next: the plan of the phase that follows, fetched in this phase's tail
 // (dvs_stage.h).  PP: plan pointer type (dvs_stage.h: plain, or into the kernel-argument segment).
-template <class PP>
+template <int NW, class PP>
 __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
                                                   bool has_next) {
     const FfnBLds l = ffnb_lds(smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 0);
     if (stage_mine) {
-        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        dvs_stage_now<(NW == 8 ? DVS_PF_BWD : DVS_PF_BWD_TAIL)>(mine, smem);
         __syncthreads();
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 1);
@@ -201,7 +202,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     dvs_bf16* const bslots = (dvs_bf16*)l.slots;                        // a [hi | lo] bf16 pair fills one fp32 scratch tile
     constexpr int BSTRIDE = 2 * 2 * DVS_SCR;                            // bf16 elements between the slots of two waves
     dvs_stagger(L.wave);
-    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+    for (int base = dvs_bid() * NW; base < B; base += gridDim.x * NW) {
         const int dag = base + L.wave;                     // tile index
         const bool live = dag < B;
         const size_t dg = live ? dag : 0;
@@ -291,8 +292,8 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     float* const buf1 = dvs_bwd_epi(smem);             // one 64 x 64 staging buffer per matrix, then the vector sums
     float* const buf2 = buf1 + 4096;
     float* red = buf2 + 4096;                         // [8 waves][6][64]
-    dvs_coop_stage(buf1, aW1, L);
-    dvs_coop_stage(buf2, aW2, L);
+    dvs_coop_stage<NW>(buf1, aW1, L);
+    dvs_coop_stage<NW>(buf2, aW2, L);
     red[(L.wave * 6 + 0) * 64 + L.lane] = 0.f;
     red[(L.wave * 6 + 1) * 64 + L.lane] = 0.f;
     red[(L.wave * 6 + 2) * 64 + L.lane] = vgam;
@@ -308,12 +309,12 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         }
     }
     dvs_lds_barrier();
-    dvs_coop_flush(buf1, slab + a.o_l1_w, aW1, L);
-    dvs_coop_flush(buf2, slab + a.o_l2_w, aW2, L);
-    if (dvs_tid() < 6 * 64) {
-        const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
+    dvs_coop_flush<NW>(buf1, slab + a.o_l1_w, aW1, L);
+    dvs_coop_flush<NW>(buf2, slab + a.o_l2_w, aW2, L);
+    for (int k = dvs_tid() >> 6; k < 6; k += NW) {          // one wave per vector (8 waves: the first six, one pass)
+        const int f = dvs_tid() & 63;
         float s = 0.f;
-        for (int w = 0; w < 8; ++w) s += red[(w * 6 + k) * 64 + f];
+        for (int w = 0; w < NW; ++w) s += red[(w * 6 + k) * 64 + f];
         const int64_t off = k == 0 ? a.o_l1_b : k == 1 ? a.o_l2_b : k == 2 ? a.o_ln_g : k == 3 ? a.o_ln_b : k == 4 ? a.o_own_g : a.o_own_b;
         if (off >= 0) slab[off + f] = s;
     }
@@ -330,7 +331,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
 // 8 waves per workgroup in two independent groups of four; weight gradients accumulated cooperatively (dvs_coop_dw_bf):
 // per wave 16 accumulator registers per projection, ~130 VGPRs, two waves per SIMD.  LDS slots per wave: X (kept for
 // all projections of the DAG) and two alternating dY slots, so one group barrier per projection + one per DAG.
-template <int NPROJ, class PP>
+template <int NPROJ, int NW, class PP>
 __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
                                                    bool has_next) {
     // W_p^T as bf16x3 images (dvs_bf16.h): dX^T = sum_p W_p^T dY_p^T is a pure gradient product (no mask or statistic
@@ -345,7 +346,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     int* gcount = pl.gcount;
     DVS_STAMP(dvs_stamps_bwd, mine, 0);
     if (stage_mine) {
-        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        dvs_stage_now<(NW == 8 ? DVS_PF_BWD : DVS_PF_BWD_TAIL)>(mine, smem);
         __syncthreads();
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 1);
@@ -364,7 +365,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
         for (int i = 0; i < 4; ++i) aW[p][i] = f4_zero();
     }
     dvs_stagger(L.wave);
-    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+    for (int base = dvs_bid() * NW; base < B; base += gridDim.x * NW) {
         const int dag = base + L.wave;               // tile index
         const bool live = dag < B;
         const size_t dg = live ? dag : 0;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     const bool so = a.slot_order != 0;
     float* const bufs = dvs_bwd_epi(smem);             // NPROJ staging buffers of 4096 floats, then the vector sums
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) dvs_coop_stage(bufs + 4096 * p, aW[p], L);
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_stage<NW>(bufs + 4096 * p, aW[p], L);
     float* red = bufs + 4096 * NPROJ;                 // [8 waves][NPROJ + 2][64]
     // bias gradients: wave (group, ot) holds the sums of features 16*ot + 4g + reg (every column r the same)
 #pragma unroll
@@ -441,11 +442,11 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     }
     dvs_lds_barrier();
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p) dvs_coop_flush(bufs + 4096 * p, slab + a.o_w + 4096 * p, aW[p], L, so, false);
-    if (dvs_tid() < (NPROJ + 2) * 64) {
-        const int k = dvs_tid() >> 6, f = dvs_tid() & 63;
+    for (int p = 0; p < NPROJ; ++p) dvs_coop_flush<NW>(bufs + 4096 * p, slab + a.o_w + 4096 * p, aW[p], L, so, false);
+    for (int k = dvs_tid() >> 6; k < NPROJ + 2; k += NW) {
+        const int f = dvs_tid() & 63;
         float s = 0.f;
-        for (int w = 0; w < 8; ++w) s += red[(w * (NPROJ + 2) + k) * 64 + f];
+        for (int w = 0; w < NW; ++w) s += red[(w * (NPROJ + 2) + k) * 64 + f];
         if (k < NPROJ) slab[a.o_b + 64 * k + (so ? dvs_pi(f) : f)] = s;
         else if (a.o_ln_g >= 0) slab[(k == NPROJ ? a.o_ln_g : a.o_ln_b) + f] = s;
     }
@@ -521,13 +522,13 @@ __device__ __forceinline__ f4 mask_S(const ProbMask& m, int h, const DvsDrop& D)
 // 8 waves per workgroup in two independent groups of four (dvs_backward.h); one DAG per wave per iteration.  The
 // out-projection gradient is accumulated cooperatively from the parked d y and O tiles, d q / d k / d v tiles are stored
 // as soon as their head pair is finished, so a wave stays within 256 registers and two waves share each SIMD.
-template <class PP>
+template <int NW, class PP>
 __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* smem, PP mine, bool stage_mine, PP next,
                                                    bool has_next) {
     const AttnBLds l = attnb_lds(smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 0);
     if (stage_mine) {
-        dvs_stage_now<DVS_PF_BWD>(mine, smem);
+        dvs_stage_now<(NW == 8 ? DVS_PF_BWD : DVS_PF_BWD_TAIL)>(mine, smem);
         __syncthreads();
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 1);
@@ -542,7 +543,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     f4 abo = f4_zero();                           // d out_proj.bias, rows 16*(wave&3).. like aWo
     dvs_stagger(L.wave);
-    for (int base = dvs_bid() * 8; base < B; base += gridDim.x * 8) {
+    for (int base = dvs_bid() * NW; base < B; base += gridDim.x * NW) {
         const int dag = base + L.wave;
         const bool live = dag < B;
         const size_t dg = live ? dag : 0;
@@ -774,7 +775,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     float* slab = a.slab + (size_t)dvs_bid() * a.P;
     float* const bufo = dvs_bwd_epi(smem);
     float* red = bufo + 4096;
-    dvs_coop_stage(bufo, aWo, L);
+    dvs_coop_stage<NW>(bufo, aWo, L);
     red[L.wave * 64 + L.lane] = 0.f;
     dvs_wave_sync();
     if (L.r == 0) {
@@ -782,10 +783,10 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         for (int reg = 0; reg < 4; ++reg) red[L.wave * 64 + 16 * (L.wave & 3) + 4 * L.g + reg] = abo[reg];
     }
     dvs_lds_barrier();
-    dvs_coop_flush(bufo, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
+    dvs_coop_flush<NW>(bufo, slab + a.o_out_w, aWo, L, false, true);     // columns back to parameter order
     if (dvs_tid() < 64) {
         float s = 0.f;
-        for (int w = 0; w < 8; ++w) s += red[w * 64 + dvs_tid()];
+        for (int w = 0; w < NW; ++w) s += red[w * 64 + dvs_tid()];
         slab[a.o_out_b + dvs_tid()] = s;
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 5);

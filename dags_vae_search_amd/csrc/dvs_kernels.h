@@ -114,7 +114,7 @@ struct BuildArgs {
 };
 void dvs_launch_build_records(const BuildArgs& a, dvs_stream_t st);
 void dvs_launch_pack(const PackArgs& a, dvs_stream_t st);
-void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, int nw, dvs_stream_t st);
 // One phase of a chained forward launch (k_fwd_stack, k_forward.hip): attention or FFN sublayer of the one-tile path.
 // DVS_FPH_LATENT (encoder chain only, last phase): the latent block on the 16 DAGs the workgroup owns (dvs_latent.h).
 enum { DVS_FPH_ATTN = 0, DVS_FPH_FFN = 1, DVS_FPH_LATENT = 2 };
@@ -133,12 +133,13 @@ struct FwdStackArgs {
     DvsStagePlan plan[DVS_FWD_STACK_PHASES];     // filled by dvs_launch_fwd_stack (dvs_stage.h)
 };
 static_assert(sizeof(FwdStackArgs) <= 4096, "kernel argument block limit");
-void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, dvs_stream_t st);   // tag 0 encoder, 1 decoder (profile names)
-void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st);
+// nw: waves per workgroup, 8 or 4 (dvs_api.hip: dvs_waves_per_wg); grid sized for nw DAGs per workgroup and pass
+void dvs_launch_fwd_stack(const FwdStackArgs& s, int tag, int grid, int nw, dvs_stream_t st);   // tag 0 encoder, 1 decoder (profile names)
+void dvs_launch_attn_fwd(const AttnArgs& a, int grid, int nw, dvs_stream_t st);
 int dvs_attn_fwd_waves();
-void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, int nw, dvs_stream_t st);
 void dvs_launch_latent_fwd(const LatentArgs& a, dvs_stream_t st);
-void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st);
+void dvs_launch_loss_fwd(const LossArgs& a, int grid, int nw, dvs_stream_t st);
 void dvs_launch_finalize(const FinalizeArgs& a, dvs_stream_t st);
 void dvs_launch_unfrag(const float* frag, float* out, int B, dvs_stream_t st);
 
@@ -150,14 +151,17 @@ void dvs_prof_end(dvs_stream_t st);
 // first failure inside one entry-point call is kept per thread (dvs_note_hip_error) and becomes that call's return code
 // and dvs_last_error() message (dvs_api.hip: call_begin / call_end).
 void dvs_note_hip_error(const char* what, int hip_error, const char* hip_message);
-#define DVS_LAUNCH(kernel, grid, block, lds, st, ...)                                          \
+// `name`: what the launch is called in the per-kernel timing table and in error messages (template instances that differ
+// only in their workgroup width share one name)
+#define DVS_LAUNCH_AS(name, kernel, grid, block, lds, st, ...)                                 \
     do {                                                                                       \
-        dvs_prof_begin(#kernel, st);                                                           \
+        dvs_prof_begin(name, st);                                                              \
         hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                         \
         const hipError_t dvs_le_ = hipGetLastError();                                          \
-        if (dvs_le_ != hipSuccess) dvs_note_hip_error(#kernel, (int)dvs_le_, hipGetErrorString(dvs_le_)); \
+        if (dvs_le_ != hipSuccess) dvs_note_hip_error(name, (int)dvs_le_, hipGetErrorString(dvs_le_)); \
         dvs_prof_end(st);                                                                      \
     } while (0)
+#define DVS_LAUNCH(kernel, grid, block, lds, st, ...) DVS_LAUNCH_AS(#kernel, kernel, grid, block, lds, st, __VA_ARGS__)
 
 #ifndef DVS_EMU
 // Raise a kernel's dynamic-LDS limit once per (call site, device): hipFuncSetAttribute costs several microseconds of

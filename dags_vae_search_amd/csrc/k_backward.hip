@@ -2,51 +2,69 @@
 #include "dvs_bwd_phases.h"
 #include "dvs_latent_bwd.h"
 
-__global__ __launch_bounds__(512) void k_ffn_bwd(FfnBwdArgs a, DvsStagePlan plan) {
+// NW = waves per workgroup (dvs_api.hip: dvs_waves_per_wg): 8 — two cooperative groups, two waves per SIMD — or 4, the narrow
+// mapping for batches that do not fill the chip at 8 DAGs per workgroup (one group, one wave per SIMD, twice the workgroups).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ffn_bwd(FfnBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_ffn_bwd_phase(a, smem, &plan, true, &plan, false);
+    dvs_ffn_bwd_phase<NW>(a, smem, &plan, true, &plan, false);
 }
-void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, dvs_stream_t st) {
+void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, int nw, dvs_stream_t st) {
     const size_t lds = ffnb_lds_bytes();
     DvsStagePlan plan;
     ffnb_plan(plan, a, DVS_FAKE_LDS);
-    DVS_SET_LDS(k_ffn_bwd, lds);
-    DVS_LAUNCH(k_ffn_bwd, dim3(grid), dim3(512), lds, st, a, plan);
-}
-
-template <int NPROJ>
-__global__ __launch_bounds__(512) void k_proj_bwd(ProjBwdArgs a, DvsStagePlan plan) {
-    DVS_DYN_LDS(smem);
-    dvs_proj_bwd_phase<NPROJ>(a, smem, &plan, true, &plan, false);
-}
-
-void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, dvs_stream_t st) {
-    const size_t bytes = projb_lds_bytes(nproj);
-    DvsStagePlan plan;
-    projb_plan(plan, a, nproj, DVS_FAKE_LDS);
-    if (nproj == 3) {
-        DVS_SET_LDS(k_proj_bwd<3>, bytes);
-        DVS_LAUNCH(k_proj_bwd<3>, dim3(grid), dim3(512), bytes, st, a, plan);
-    } else if (nproj == 2) {
-        DVS_SET_LDS(k_proj_bwd<2>, bytes);
-        DVS_LAUNCH(k_proj_bwd<2>, dim3(grid), dim3(512), bytes, st, a, plan);
+    if (nw == 4) {
+        DVS_SET_LDS(k_ffn_bwd<4>, lds);
+        DVS_LAUNCH_AS("k_ffn_bwd", k_ffn_bwd<4>, dim3(grid), dim3(256), lds, st, a, plan);
     } else {
-        DVS_SET_LDS(k_proj_bwd<1>, bytes);
-        DVS_LAUNCH(k_proj_bwd<1>, dim3(grid), dim3(512), bytes, st, a, plan);
+        DVS_SET_LDS(k_ffn_bwd<8>, lds);
+        DVS_LAUNCH_AS("k_ffn_bwd", k_ffn_bwd<8>, dim3(grid), dim3(512), lds, st, a, plan);
     }
 }
 
-__global__ __launch_bounds__(512) void k_attn_bwd(AttnBwdArgs a, DvsStagePlan plan) {
+template <int NPROJ, int NW>
+__global__ __launch_bounds__(64 * NW) void k_proj_bwd(ProjBwdArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_attn_bwd_phase(a, smem, &plan, true, &plan, false);
+    dvs_proj_bwd_phase<NPROJ, NW>(a, smem, &plan, true, &plan, false);
 }
 
-void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
+#define DVS_PROJ_LAUNCH(NP, NWV)                                                               \
+    do {                                                                                       \
+        DVS_SET_LDS((k_proj_bwd<NP, NWV>), bytes);                                             \
+        DVS_LAUNCH_AS("k_proj_bwd<" #NP ">", (k_proj_bwd<NP, NWV>), dim3(grid), dim3(64 * NWV), bytes, st, a, plan); \
+    } while (0)
+void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, int nw, dvs_stream_t st) {
+    const size_t bytes = projb_lds_bytes(nproj);
+    DvsStagePlan plan;
+    projb_plan(plan, a, nproj, DVS_FAKE_LDS);
+    if (nw == 4) {
+        if (nproj == 3) DVS_PROJ_LAUNCH(3, 4);
+        else if (nproj == 2) DVS_PROJ_LAUNCH(2, 4);
+        else DVS_PROJ_LAUNCH(1, 4);
+    } else {
+        if (nproj == 3) DVS_PROJ_LAUNCH(3, 8);
+        else if (nproj == 2) DVS_PROJ_LAUNCH(2, 8);
+        else DVS_PROJ_LAUNCH(1, 8);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_bwd(AttnBwdArgs a, DvsStagePlan plan) {
+    DVS_DYN_LDS(smem);
+    dvs_attn_bwd_phase<NW>(a, smem, &plan, true, &plan, false);
+}
+
+void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, int nw, dvs_stream_t st) {
     const size_t lds = attnb_lds_floats() * 4;
     DvsStagePlan plan;
     attnb_plan(plan, a, DVS_FAKE_LDS);
-    DVS_SET_LDS(k_attn_bwd, lds);
-    DVS_LAUNCH(k_attn_bwd, dim3(grid), dim3(512), lds, st, a, plan);
+    if (nw == 4) {
+        DVS_SET_LDS(k_attn_bwd<4>, lds);
+        DVS_LAUNCH_AS("k_attn_bwd", k_attn_bwd<4>, dim3(grid), dim3(256), lds, st, a, plan);
+    } else {
+        DVS_SET_LDS(k_attn_bwd<8>, lds);
+        DVS_LAUNCH_AS("k_attn_bwd", k_attn_bwd<8>, dim3(grid), dim3(512), lds, st, a, plan);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -54,8 +72,8 @@ void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
 // on this part (dispatch + end-of-kernel cache write-back) against 20-50 us of work per phase; the phases of a chain
 // need nothing from each other but the workgroup's own tiles.  TAG only names the launch in profiles.
 // ---------------------------------------------------------------------------------------------------------
-template <int TAG>
-__global__ __launch_bounds__(512) void k_bwd_stack(BwdStackArgs s) {
+template <int TAG, int NW>
+__global__ __launch_bounds__(64 * NW) void k_bwd_stack(BwdStackArgs s) {
     DVS_DYN_LDS(smem);
     // the plan table is read straight from the kernel-argument segment (dvs_stage.h); the struct is the kernel's only
     // explicit argument, so it starts at offset 0 of the segment
@@ -65,7 +83,7 @@ __global__ __launch_bounds__(512) void k_bwd_stack(BwdStackArgs s) {
 #else
     const DvsPlanK plans = s.plan;
 #endif
-    if (TAG == 1 && s.has_latent) {
+    if (TAG == 1 && NW == 8 && s.has_latent) {
         // latent block on the workgroup's DAGs, two 8-DAG runs (= two rounds of the phases' DAG loops) per MFMA group; its
         // d enc_out tiles are read by other waves of this workgroup in phase 0: __syncthreads waits for the stores (vmcnt)
         const int step = (int)gridDim.x * 8, B = s.lat.dims.B;
@@ -81,17 +99,17 @@ __global__ __launch_bounds__(512) void k_bwd_stack(BwdStackArgs s) {
         const DvsPlanK mine = plans + i;
         const DvsPlanK next = plans + (more ? i + 1 : i);
         switch (ph.kind) {
-            case DVS_PH_FFN: dvs_ffn_bwd_phase(ph.u.f, smem, mine, first, next, more); break;
-            case DVS_PH_ATTN: dvs_attn_bwd_phase(ph.u.a, smem, mine, first, next, more); break;
-            case DVS_PH_PROJ1: dvs_proj_bwd_phase<1>(ph.u.p, smem, mine, first, next, more); break;
-            case DVS_PH_PROJ2: dvs_proj_bwd_phase<2>(ph.u.p, smem, mine, first, next, more); break;
-            default: dvs_proj_bwd_phase<3>(ph.u.p, smem, mine, first, next, more); break;
+            case DVS_PH_FFN: dvs_ffn_bwd_phase<NW>(ph.u.f, smem, mine, first, next, more); break;
+            case DVS_PH_ATTN: dvs_attn_bwd_phase<NW>(ph.u.a, smem, mine, first, next, more); break;
+            case DVS_PH_PROJ1: dvs_proj_bwd_phase<1, NW>(ph.u.p, smem, mine, first, next, more); break;
+            case DVS_PH_PROJ2: dvs_proj_bwd_phase<2, NW>(ph.u.p, smem, mine, first, next, more); break;
+            default: dvs_proj_bwd_phase<3, NW>(ph.u.p, smem, mine, first, next, more); break;
         }
         dvs_lds_barrier();   // publishes the next phase's staged images (tail commit); global tiles: same wave, same queue
     }
 }
 
-void dvs_launch_bwd_stack(const BwdStackArgs& s_in, int tag, int grid, dvs_stream_t st) {
+void dvs_launch_bwd_stack(const BwdStackArgs& s_in, int tag, int grid, int nw, dvs_stream_t st) {
     BwdStackArgs s = s_in;
     for (int i = 0; i < s.nphase; ++i) {
         dvs_bwd_plan(s.plan[i], s.ph[i], DVS_FAKE_LDS);
@@ -108,12 +126,17 @@ void dvs_launch_bwd_stack(const BwdStackArgs& s_in, int tag, int grid, dvs_strea
         const size_t b = k == DVS_PH_FFN ? ffnb_lds_bytes() : k == DVS_PH_ATTN ? attnb_lds_floats() * 4 : projb_lds_bytes(k - DVS_PH_PROJ1 + 1);
         lds = b > lds ? b : lds;
     }
-    if (tag == 0) {
-        DVS_SET_LDS(k_bwd_stack<0>, lds);
-        DVS_LAUNCH(k_bwd_stack<0>, dim3(grid), dim3(512), lds, st, s);
+#define DVS_BSTACK_LAUNCH(TG, NWV)                                                             \
+    do {                                                                                       \
+        DVS_SET_LDS((k_bwd_stack<TG, NWV>), lds);                                              \
+        DVS_LAUNCH_AS("k_bwd_stack<" #TG ">", (k_bwd_stack<TG, NWV>), dim3(grid), dim3(64 * NWV), lds, st, s); \
+    } while (0)
+    if (nw == 4) {
+        if (tag == 0) DVS_BSTACK_LAUNCH(0, 4);
+        else DVS_BSTACK_LAUNCH(1, 4);
     } else {
-        DVS_SET_LDS(k_bwd_stack<1>, lds);
-        DVS_LAUNCH(k_bwd_stack<1>, dim3(grid), dim3(512), lds, st, s);
+        if (tag == 0) DVS_BSTACK_LAUNCH(0, 8);
+        else DVS_BSTACK_LAUNCH(1, 8);
     }
 }
 

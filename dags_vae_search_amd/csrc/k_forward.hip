@@ -243,7 +243,9 @@ __global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a, DvsStagePlan pl
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
     const EmbLds l = emb_lds(smem);
-    dvs_stage_now<2>(&plan, smem);           // the embedding block (dvs_wimg.h) in one batch: 20 wave chunks on 16 waves
+    // the embedding block (dvs_wimg.h) in one batch: 20 wave chunks on 16 waves (4 in the narrow mapping of small batches)
+    if (blockDim.x >= 1024) dvs_stage_now<2>(&plan, smem);
+    else dvs_stage_now<5>(&plan, smem);
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -296,14 +298,14 @@ __global__ __launch_bounds__(1024) void k_embed_fwd(EmbedArgs a, DvsStagePlan pl
     }
 }
 
-void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, dvs_stream_t st) {
+void dvs_launch_embed_fwd(const EmbedArgs& a, int grid, int nw, dvs_stream_t st) {      // nw: 16 waves per workgroup, or 4
     const size_t lds = emb_lds_floats(16) * 4;
     DvsStagePlan plan;
     dvs_plan_clear(plan);
     dvs_plan_seg(plan, DVS_FAKE_LDS, DVS_FAKE_LDS, a.embimg, 2 * DvsEmbImg::FLOATS);
     dvs_plan_seal(plan);
     DVS_SET_LDS(k_embed_fwd, lds);
-    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(1024), lds, st, a, plan);
+    DVS_LAUNCH(k_embed_fwd, dim3(grid), dim3(nw == 4 ? 256 : 1024), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -441,13 +443,15 @@ __device__ __forceinline__ f4 attn_drop_T(f4 p, uint32_t key, int h, const DvsDr
 #endif
 // mine / stage_mine, next / has_next: staging plans of this phase and of the one that follows in a chained launch
 // (dvs_stage.h): the next phase's images are fetched into registers behind this phase's DAG loop, ahead of the barrier.
-template <class PP>
+// NW: waves per workgroup the phase is compiled for (8, or 4 in the narrow mapping of small batches, dvs_api.hip): sizes the
+// first phase's staging batch; the DAG loop itself reads the workgroup width at run time (L.nwaves)
+template <int NW, class PP>
 __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem, PP mine, bool stage_mine, PP next,
                                                    bool has_next) {
     const AttnLds l = attn_lds(smem);
     DVS_STAMP(dvs_stamps_fwd, mine, 0);
     if (stage_mine) {
-        dvs_stage_now<DVS_PF_FWD>(mine, smem);
+        dvs_stage_now<(NW >= 8 ? DVS_PF_FWD : DVS_PF_FWD_TAIL)>(mine, smem);
         __syncthreads();
     }
     DVS_STAMP(dvs_stamps_fwd, mine, 1);
@@ -545,18 +549,24 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
     }
 }
 
-__global__ __launch_bounds__(DVS_ATTN_FWD_THREADS) void k_attn_fwd(AttnArgs a, DvsStagePlan plan) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_fwd(AttnArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
-    dvs_attn_fwd_phase(a, smem, &plan, true, &plan, false);
+    dvs_attn_fwd_phase<NW>(a, smem, &plan, true, &plan, false);
 }
 
 int dvs_attn_fwd_waves() { return DVS_ATTN_FWD_THREADS / 64; }
-void dvs_launch_attn_fwd(const AttnArgs& a, int grid, dvs_stream_t st) {
+void dvs_launch_attn_fwd(const AttnArgs& a, int grid, int nw, dvs_stream_t st) {
     const size_t lds = attn_lds_bytes();
     DvsStagePlan plan;
     attn_plan(plan, a, DVS_FAKE_LDS);
-    DVS_SET_LDS(k_attn_fwd, lds);
-    DVS_LAUNCH(k_attn_fwd, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a, plan);
+    if (nw == 4) {
+        DVS_SET_LDS(k_attn_fwd<4>, lds);
+        DVS_LAUNCH_AS("k_attn_fwd", k_attn_fwd<4>, dim3(grid), dim3(256), lds, st, a, plan);
+    } else {
+        DVS_SET_LDS(k_attn_fwd<DVS_ATTN_FWD_THREADS / 64>, lds);
+        DVS_LAUNCH_AS("k_attn_fwd", k_attn_fwd<DVS_ATTN_FWD_THREADS / 64>, dim3(grid), dim3(DVS_ATTN_FWD_THREADS), lds, st, a, plan);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -674,18 +684,19 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, 
     }
 }
 
-// 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.
+// 16 waves per workgroup (4 waves per SIMD): at B = 4096 every wave owns exactly one DAG.  nw = 4 (narrow mapping): the
+// same kernel on 4 waves — DVS_PF_FWD slots per thread cover the 54 wave chunks of the FFN images from 4 waves up.
 __global__ __launch_bounds__(1024) void k_ffn_fwd(FfnArgs a, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
     dvs_ffn_fwd_phase(a, smem, &plan, true, &plan, false);
 }
 
-void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
+void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, int nw, dvs_stream_t st) {
     const size_t lds = ffn_lds_bytes();
     DvsStagePlan plan;
     ffn_plan(plan, a, DVS_FAKE_LDS);
     DVS_SET_LDS(k_ffn_fwd, lds);
-    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(1024), lds, st, a, plan);
+    DVS_LAUNCH(k_ffn_fwd, dim3(grid), dim3(nw == 4 ? 256 : 1024), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -693,8 +704,8 @@ void dvs_launch_ffn_fwd(const FfnArgs& a, int grid, dvs_stream_t st) {
 // workgroup.  Both phase kinds map tile `blockIdx.x * 8 + wave (+ gridDim.x * 8 ...)` to the same wave, so a phase reads
 // tiles and LayerNorm statistics its own workgroup wrote; a workgroup barrier is the only synchronisation (k_bwd_stack).
 // ---------------------------------------------------------------------------------------------------------
-template <int TAG>
-__global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
+template <int TAG, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd_stack(FwdStackArgs s) {
     DVS_DYN_LDS(smem);
     // the plan table is read straight from the kernel-argument segment (dvs_stage.h): the struct is the only explicit argument
 #ifndef DVS_EMU
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
         const FwdPhase& ph = s.ph[i];
         const bool first = i == 0, more = i + 1 < s.nphase;
         const DvsPlanK mine = plans + i;
-        if (TAG == 0 && ph.kind == DVS_FPH_LATENT) {
+        if (TAG == 0 && NW == 8 && ph.kind == DVS_FPH_LATENT) {
             // the workgroup's DAGs, two 8-DAG runs (= two rounds of the phases' DAG loops) per group; the encoder output tiles
             // were written by other waves of this workgroup: __syncthreads waits for every wave's stores (vmcnt) first
             const int step = (int)gridDim.x * 8, B = ph.u.l.dims.B;
@@ -719,13 +730,13 @@ __global__ __launch_bounds__(512) void k_fwd_stack(FwdStackArgs s) {
         }
         const bool more_img = more && s.ph[i + 1].kind != DVS_FPH_LATENT;      // the latent phase stages nothing
         const DvsPlanK next = plans + (more_img ? i + 1 : i);
-        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase(ph.u.a, smem, mine, first, next, more_img);
+        if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase<NW>(ph.u.a, smem, mine, first, next, more_img);
         else dvs_ffn_fwd_phase(ph.u.f, smem, mine, first, next, more_img);
         dvs_lds_barrier();               // publishes the next phase's staged images
     }
 }
 
-void dvs_launch_fwd_stack(const FwdStackArgs& s_in, int tag, int grid, dvs_stream_t st) {
+void dvs_launch_fwd_stack(const FwdStackArgs& s_in, int tag, int grid, int nw, dvs_stream_t st) {
     FwdStackArgs s = s_in;
     for (int i = 0; i < s.nphase; ++i) {
         if (s.ph[i].kind == DVS_FPH_ATTN) attn_plan(s.plan[i], s.ph[i].u.a, DVS_FAKE_LDS);
@@ -738,12 +749,17 @@ void dvs_launch_fwd_stack(const FwdStackArgs& s_in, int tag, int grid, dvs_strea
 #endif
     const size_t la = attn_lds_bytes(), lf = ffn_lds_bytes();
     const size_t lds = la > lf ? la : lf;
-    if (tag == 0) {
-        DVS_SET_LDS(k_fwd_stack<0>, lds);
-        DVS_LAUNCH(k_fwd_stack<0>, dim3(grid), dim3(512), lds, st, s);
+#define DVS_FSTACK_LAUNCH(TG, NWV)                                                             \
+    do {                                                                                       \
+        DVS_SET_LDS((k_fwd_stack<TG, NWV>), lds);                                              \
+        DVS_LAUNCH_AS("k_fwd_stack<" #TG ">", (k_fwd_stack<TG, NWV>), dim3(grid), dim3(64 * NWV), lds, st, s); \
+    } while (0)
+    if (nw == 4) {
+        if (tag == 0) DVS_FSTACK_LAUNCH(0, 4);
+        else DVS_FSTACK_LAUNCH(1, 4);
     } else {
-        DVS_SET_LDS(k_fwd_stack<1>, lds);
-        DVS_LAUNCH(k_fwd_stack<1>, dim3(grid), dim3(512), lds, st, s);
+        if (tag == 0) DVS_FSTACK_LAUNCH(0, 8);
+        else DVS_FSTACK_LAUNCH(1, 8);
     }
 }
 

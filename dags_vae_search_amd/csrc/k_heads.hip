@@ -56,7 +56,9 @@ __global__ __launch_bounds__(512) void k_loss_fwd(LossArgs a, DvsStagePlan plan)
 #endif
     DVS_DYN_LDS(smem);
     const LossLds l = loss_lds(smem);
-    dvs_stage_now<(LOSS_CHUNKS + 7) / 8>(&plan, smem);        // the whole loss block in one batch of loads
+    // the whole loss block in one batch of loads (8 waves per workgroup; 4 in the narrow mapping of small batches)
+    if (blockDim.x >= 512) dvs_stage_now<(LOSS_CHUNKS + 7) / 8>(&plan, smem);
+    else dvs_stage_now<(LOSS_CHUNKS + 3) / 4>(&plan, smem);
     __syncthreads();
     const Lane L = dvs_lane();
     const int N = a.dims.N, C = a.dims.C;
@@ -154,12 +156,12 @@ __global__ __launch_bounds__(512) void k_loss_fwd(LossArgs a, DvsStagePlan plan)
     }
 }
 
-void dvs_launch_loss_fwd(const LossArgs& a, int grid, dvs_stream_t st) {
+void dvs_launch_loss_fwd(const LossArgs& a, int grid, int nw, dvs_stream_t st) {
     const size_t lds = loss_lds_bytes(8, 1);
     DvsStagePlan plan;
     loss_plan(plan, a);
     DVS_SET_LDS(k_loss_fwd, lds);
-    DVS_LAUNCH(k_loss_fwd, dim3(grid), dim3(512), lds, st, a, plan);
+    DVS_LAUNCH(k_loss_fwd, dim3(grid), dim3(nw == 4 ? 256 : 512), lds, st, a, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -12,6 +12,15 @@ from tests.emu.harness import EmuModel, ptr
 from tests.helpers import load_golden, rel
 
 
+@pytest.fixture(params=[4, 8])
+def waves_per_wg(request, monkeypatch):
+    """Both workgroup widths of the one-tile stack kernels (dvs_api.hip: waves_per_wg): 8 waves = two cooperative groups,
+    4 = the narrow mapping of small batches.  The emulator has 2 'CUs', so without the switch every small test batch would
+    take the narrow one only."""
+    monkeypatch.setenv("DVS_WAVES_PER_WG", str(request.param))
+    return request.param
+
+
 def _oracle_grads(cfg, params, f_np, **kw):
     P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     total, recon, kld = po.loss_direct(P, cfg, ofeat.to_torch(f_np), **kw)
@@ -28,7 +37,7 @@ def _check_grads(got, ref, tol):
 
 @pytest.mark.parametrize("name,B", [("n12c12", 5), ("asia_rand", 6), ("n12c1", 3), ("n37c37", -4),
                                     ("n13c5", -3), ("n14c14", -3), ("n29c7", -3), ("n45c45", -3)])
-def test_emu_gradients_eval(name, B):
+def test_emu_gradients_eval(name, B, waves_per_wg):
     """Eval-mode gradients against the oracle on a slice of the fixture's graphs (the reference's own gradients of the
     full fixtures are checked on the GPU and by tests/test_oracle.py); negative B = the LAST graphs of the fixture (the
     path / star DAGs of the alarm-size and edge-shape fixtures)."""
@@ -46,7 +55,7 @@ def test_emu_gradients_eval(name, B):
 
 
 @pytest.mark.parametrize("name,B,seed", [("n12c12", 6, 1234), ("asia_rand", 4, 99), ("n37c37", 3, 4321)])
-def test_emu_train_mode_with_dropout_and_hashed_eps(name, B, seed):
+def test_emu_train_mode_with_dropout_and_hashed_eps(name, B, seed, waves_per_wg):
     """dropout 0.15 + counter-based eps: the oracle runs with the device's masks (oracle/rng.py)."""
     cfg, params, graphs, z = load_golden(name)
     f_np = ofeat.dense_features(graphs[:B], cfg.card)
@@ -111,7 +120,7 @@ def test_emu_train0_golden_and_adam_step():
     assert worst_big < 1e-6
 
 
-def test_emu_batch_sharding_is_additive():
+def test_emu_batch_sharding_is_additive(waves_per_wg):
     """Data-parallel property: loss and gradients of a batch equal the SUM over shards that keep the
     global DAG index (dag_offset) — also with dropout on."""
     cfg, params, graphs, z = load_golden("n12c12")

@@ -9,9 +9,11 @@ from tests.emu.harness import EmuModel
 from tests.helpers import load_golden, rel
 
 
+@pytest.mark.parametrize("nw", [4, 8])
 @pytest.mark.parametrize("name,B", [("n12c12", 6), ("asia_rand", 5), ("n12c1", 4), ("n37c37", -5),
                                     ("n13c5", -4), ("n14c14", -3), ("n29c7", -3), ("n45c45", -3)])
-def test_emu_forward_eval_matches_oracle(name, B):
+def test_emu_forward_eval_matches_oracle(name, B, nw, monkeypatch):
+    monkeypatch.setenv("DVS_WAVES_PER_WG", str(nw))          # both workgroup widths of the one-tile stack (dvs_api.hip)
     cfg, params, graphs, z = load_golden(name)
     graphs = graphs[:B] if B > 0 else graphs[B:]          # n37c37: the last ones are the chain / star DAGs
     f_np = ofeat.dense_features(graphs, cfg.card)

@@ -41,7 +41,7 @@ m.eval()
 mu, logvar = m.encode_direct(f)
 h.update(mu.cpu().numpy().tobytes())
 print("DIGEST", h.hexdigest(), loss_value)
-print("VALUES", float(losses[0]), float(g0.norm()), float(g0.abs().max()), float(m.flat_params.double().sum()))
+print("VALUES", float(losses[0]), float(g0.norm()), float(g0.abs().max()), float(loss_value))
 """
 
 
@@ -62,7 +62,7 @@ def test_chained_and_split_launches_agree_bitwise():
     launches (DVS_LATENT_KERNELS=1) — the 1000-DAG batch leaves the chains' last MFMA group half empty.  Both workgroup
     widths of the stack kernels (dvs_api.hip: waves_per_wg — 8 waves, and the narrow 4-wave mapping this batch size would
     pick by itself): chained == split bit for bit within a width; across widths the summation order of the weight gradients
-    differs, so loss, gradient norm and the parameters after three steps agree to rounding."""
+    differs, so loss, gradient norm / maximum and the third train step's loss agree to rounding."""
     (chained, v8), (split, _), (own_latent, _) = run_child(False), run_child(True), run_child(False, latent_kernels=True)
     assert chained == split
     assert chained == own_latent
@@ -70,4 +70,4 @@ def test_chained_and_split_launches_agree_bitwise():
     assert chained4 == split4
     assert abs(v4[0] - v8[0]) <= 1e-6 * abs(v8[0])                  # loss: per-DAG values are identical, the sum order too
     assert abs(v4[1] - v8[1]) <= 1e-5 * v8[1] and abs(v4[2] - v8[2]) <= 1e-4 * v8[2]
-    assert abs(v4[3] - v8[3]) <= 1e-3 * max(1.0, abs(v8[3]))
+    assert abs(v4[3] - v8[3]) <= 1e-4 * abs(v8[3])                  # the loss of the third train step

@@ -17,9 +17,10 @@ D_MODEL, HEADS, LAYERS, LATENT, FC_HIDDEN, EMB = 64, 8, 3, 32, 32, 32
 MAX_TOKENS = 48           # 16 on the one-tile path (a wavefront owns a DAG); up to 48 on the tiled wide path
 TILE_TOKENS = 16
 DECODE_STATE_BYTES = 440
+CLIP_SCRATCH_FLOATS = 4096  # DVS_CLIP_SCRATCH_FLOATS
 RECORD_BYTES = 96         # one-tile path; record_bytes(lib, shape) gives the size that applies
 LOSS_FLOATS = 5           # DVS_LOSS_FLOATS: total, recon, kld, non-finite flag, invalid-features flag
-ABI_VERSION = 201         # DVS_VERSION of include/dvs.h this binding was written against
+ABI_VERSION = 202         # DVS_VERSION of include/dvs.h this binding was written against
 
 
 class DvsShape(Structure):
@@ -65,6 +66,10 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, gcoef, grads, stream)
     lib.dvs_loss_backward.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
                                       c_void_p, c_void_p]
+    lib.dvs_loss_backward_sq.restype = c_int
+    # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, gcoef, grads, clip_scratch, stream)
+    lib.dvs_loss_backward_sq.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]
     lib.dvs_encode.restype = c_int
     # (shape, records, records_bytes, params, n_params, workspace, workspace_bytes, mu, logvar, stream)
     lib.dvs_encode.argtypes = [P(DvsShape), c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p,
@@ -93,6 +98,8 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     # (n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard, stream)
     lib.dvs_clip_adam.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                   c_int64, c_float, c_void_p, c_void_p, c_void_p]
+    lib.dvs_clip_adam_from_partials.restype = c_int
+    lib.dvs_clip_adam_from_partials.argtypes = lib.dvs_clip_adam.argtypes
     lib.dvs_profile_enable.restype = None
     lib.dvs_profile_enable.argtypes = [c_int]
     lib.dvs_profile_collect.restype = c_int
@@ -103,8 +110,8 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
-           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_forward_notify", "dvs_loss_backward", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
-           "dvs_clip_adam", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
+           "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_forward_notify", "dvs_loss_backward", "dvs_loss_backward_sq", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
+           "dvs_clip_adam", "dvs_clip_adam_from_partials", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
 
 
 def profile_collect(lib):

@@ -86,6 +86,8 @@ struct ReduceArgs {
     int64_t P;
     int nslab;
     int64_t fc_lo1, fc_hi1, fc_lo2, fc_hi2;
+    float* sqpart;               // optional [gridDim.x]: this workgroup's sum of squares of the gradient entries it wrote — the
+                                 // partials k_adam derives the clip coefficient from (dvs_loss_backward_sq, include/dvs.h)
 };
 
 // One phase of a chained backward launch (k_bwd_stack, k_backward.hip).  Plain data: the table travels as the kernel argument.
@@ -117,8 +119,12 @@ void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st);
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st);
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st);
+// have_partials: scratch[2 ..] already holds dvs_sq_parts(n) partial sums of squares of `grads` (written by k_reduce_slabs)
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
-                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, dvs_stream_t st);
+                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, bool have_partials,
+                          dvs_stream_t st);
+// workgroups of k_reduce_slabs for an n-float gradient = partial sums of squares it leaves behind
+inline int dvs_sq_parts(int64_t n) { return (int)(((n + 3) / 4 + 63) / 64); }
 
 // ---- slab reduction helpers ---------------------------------------------------------------------------------------
 // After its DAG loop a workgroup adds its waves' register accumulators and writes ONE partial per parameter to its
@@ -315,10 +321,13 @@ __device__ __forceinline__ void dvs_ln_bwd_core(f4 (&dx)[4], const f4 (&xhat)[4]
     for (int t = 0; t < 4; ++t) dx[t] = (dx[t] - s1 - xhat[t] * s2) * rstd;
 }
 
-__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L) {
-    dvs_load_tile(g, base, dag, L);
+__device__ __forceinline__ void dvs_zero_rows(f4 (&g)[4], int N, const Lane& L) {      // rows of padding tokens (r >= N)
     if (L.r >= N) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = f4_zero();
     }
+}
+__device__ __forceinline__ void dvs_load_grad(f4 (&g)[4], const float* base, size_t dag, int N, const Lane& L) {
+    dvs_load_tile(g, base, dag, L);
+    dvs_zero_rows(g, N, L);
 }

@@ -201,6 +201,8 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     float vgam = 0.f, vbet = 0.f, vog = 0.f, vob = 0.f;                   // lane = feature
     dvs_bf16* const bslots = (dvs_bf16*)l.slots;                        // a [hi | lo] bf16 pair fills one fp32 scratch tile
     constexpr int BSTRIDE = 2 * 2 * DVS_SCR;                            // bf16 elements between the slots of two waves
+    bool gate = !stage_mine;                               // chained: the barrier that publishes this phase's images (DVS_PHASE_GATE)
+    DVS_PHASE_GATE_INIT(gate);
     dvs_stagger(L.wave);
     for (int base = dvs_bid() * NW; base < B; base += gridDim.x * NW) {
         const int dag = base + L.wave;                     // tile index
@@ -211,8 +213,14 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         const int Nl = live ? N : 0;                       // a wave without a tile carries all-zero tiles
         f4 x[4], xhat[4], gp[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
-        dvs_load_grad(gp, a.gpre, dg, Nl, L);
+        {
+            DvsRawX rx;
+            dvs_load_x_issue(rx, a.xin, a.ln, dg, L);      // the COLD load of the round (a saved forward activation; the gradient
+            DVS_PHASE_GATE(gate);                          // tile below was written by this wave one phase ago); gate: behind it,
+            dvs_load_tile(gp, a.gpre, dg, L);              // ahead of the first LDS access.  More tiles in flight across the gate
+            dvs_load_x_finish<true>(x, xhat, rstd, rx, a.ln, l.lg, l.lb, Nl, L);      // cost the 8-wave chain 14 VGPR spills
+            dvs_zero_rows(gp, Nl, L);
+        }
         if (a.own_pre) {   // incoming gradient is w.r.t. LN_own(pre_own): pull back to d(pre_own)
             f4 po[4], pxh[4], t0[4];
             float prstd;
@@ -282,6 +290,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         }
         if (live) dvs_store_tile(a.gout, dag, dx, L);
     }
+    DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
     DvsBwdTail tail;
     dvs_tail_issue(tail, next, has_next);
@@ -356,6 +365,8 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     dvs_bf16* myA1 = myA0 + 2 * DVS_PKB;
     dvs_bf16* myB = myA0 + 4 * DVS_PKB;
     DvsGroup G = {gcount + (L.wave >> 2), 0};
+    bool gate = !stage_mine;                               // chained: the barrier that publishes this phase's images (DVS_PHASE_GATE)
+    DVS_PHASE_GATE_INIT(gate);
     f4 aW[NPROJ][4], ab[NPROJ];
     float vgam = 0.f, vbet = 0.f;
 #pragma unroll
@@ -372,12 +383,18 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
         const int Nl = live ? dvs_tile_of((int)dg, a.dims).Nl : 0;
         f4 x[4], xhat[4], dx[4];
         float rstd;
-        dvs_load_x<true>(x, xhat, rstd, a.xin, a.ln, lg, lb, dg, Nl, L);
-        if (a.gres) {
-            dvs_load_grad(dx, a.gres, dg, Nl, L);
-        } else {
+        {
+            DvsRawX rx;
+            dvs_load_x_issue(rx, a.xin, a.ln, dg, L);      // the cold load of the round
+            DVS_PHASE_GATE(gate);                          // behind it, ahead of the first LDS access
+            if (a.gres) {
+                dvs_load_tile(dx, a.gres, dg, L);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
+                for (int t = 0; t < 4; ++t) dx[t] = f4_zero();
+            }
+            dvs_load_x_finish<true>(x, xhat, rstd, rx, a.ln, lg, lb, Nl, L);
+            dvs_zero_rows(dx, Nl, L);
         }
         dvs_park_bf(myB, x, L);
 #pragma unroll
@@ -416,6 +433,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
             dvs_store_tile(a.gout, dag, dx, L);
         }
     }
+    DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
     DvsBwdTail tail;
     dvs_tail_issue(tail, next, has_next);
@@ -542,6 +560,10 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     const float scale = 0.35355339059327373f;
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     f4 abo = f4_zero();                           // d out_proj.bias, rows 16*(wave&3).. like aWo
+    // chained: the barrier that publishes this phase's images — taken up front here; inside the DAG loop (behind the first
+    // round's loads, as the FFN / projection phases do) it cost this phase, which sits at the 256-register limit, 15 spills
+    bool gate = !stage_mine;
+    DVS_PHASE_GATE(gate);
     dvs_stagger(L.wave);
     for (int base = dvs_bid() * NW; base < B; base += gridDim.x * NW) {
         const int dag = base + L.wave;
@@ -555,10 +577,11 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         {
             f4 x[4], kv[4], dummy[4];
             float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
-            if (a.kv) {
-                dvs_load_tile(kv, a.kv, dg, L);
-            } else {
+            {
+                dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dg, Nl, L);
+                if (a.kv) dvs_load_tile(kv, a.kv, dg, L);
+            }
+            if (!a.kv) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) kv[t] = x[t];
             }

@@ -218,30 +218,65 @@ __device__ __forceinline__ DvsDrop dvs_drop_of(const DvsDims& d) {
 
 // Prologue shared by every sublayer kernel: load the producer's pre-sum and apply its LayerNorm.
 // Rows of padding tokens (r >= N) are forced to zero.  xhat (optional) receives the normalised value.
+// Two halves, so that a chained phase can put its opening workgroup barrier BETWEEN them (DVS_PHASE_GATE below): `issue` is
+// global loads only, `finish` is the first reader of the LayerNorm parameters in LDS.
+struct DvsRawX {
+    f4 raw[4];
+    float mean, rs;
+};
+__device__ __forceinline__ void dvs_load_x_issue(DvsRawX& r, const float* xin, const DvsLN& ln, size_t dag, const Lane& L) {
+    dvs_load_tile(r.raw, xin, dag, L);
+    r.mean = 0.f;
+    r.rs = 1.f;
+    if (ln.stats != nullptr) {
+        r.mean = ln.stats[dag * 32 + L.r];
+        r.rs = ln.stats[dag * 32 + 16 + L.r];
+    }
+}
 template <bool WANT_XHAT>
-__device__ __forceinline__ void dvs_load_x(f4 (&x)[4], f4 (&xhat)[4], float& rstd, const float* xin, const DvsLN& ln,
-                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L) {
+__device__ __forceinline__ void dvs_load_x_finish(f4 (&x)[4], f4 (&xhat)[4], float& rstd, const DvsRawX& r, const DvsLN& ln,
+                                                  const float* lg, const float* lb, int N, const Lane& L) {
     // whole-vector arithmetic only (element-wise updates of the loaded vectors inside the branch made hipcc route
     // them through scratch memory)
-    f4 raw[4];
-    dvs_load_tile(raw, xin, dag, L);
     const float vm = L.r < N ? 1.f : 0.f;
-    float mean = 0.f, rs = 1.f;
     const bool has_ln = ln.stats != nullptr;
-    if (has_ln) {
-        mean = ln.stats[dag * 32 + L.r];
-        rs = ln.stats[dag * 32 + 16 + L.r];
-    }
-    rstd = rs;
+    rstd = r.rs;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f4 g = has_ln ? dvs_vecT(lg, t, L) : f4_splat(1.f);
         const f4 b = has_ln ? dvs_vecT(lb, t, L) : f4_zero();
-        const f4 xh = (raw[t] - mean) * (rs * vm);
+        const f4 xh = (r.raw[t] - r.mean) * (r.rs * vm);
         if (WANT_XHAT) xhat[t] = has_ln ? xh : f4_zero();
         x[t] = xh * g + b * vm;
     }
 }
+template <bool WANT_XHAT>
+__device__ __forceinline__ void dvs_load_x(f4 (&x)[4], f4 (&xhat)[4], float& rstd, const float* xin, const DvsLN& ln,
+                                           const float* lg, const float* lb, size_t dag, int N, const Lane& L) {
+    DvsRawX r;
+    dvs_load_x_issue(r, xin, ln, dag, L);
+    dvs_load_x_finish<WANT_XHAT>(x, xhat, rstd, r, ln, lg, lb, N, L);
+}
+
+// Opening barrier of a chained phase.  The previous phase's tail commits this phase's images and vectors to LDS and the
+// workgroup barrier that publishes them used to sit between the two phase functions; every wave then started its first DAG
+// with a cold global load behind that barrier.  Now the phase takes the barrier itself, in its FIRST DAG round, right behind
+// that round's global loads (nothing in LDS has been touched yet — the loads are the only work ahead of it), so their latency
+// overlaps the wait for the slowest wave of the previous phase and for the commit.  `pending` is false when the phase staged
+// its own images (first phase of a launch, per-phase kernels); a workgroup without a DAG takes the barrier behind its loop.
+// -DDVS_GATE_UPFRONT (A/B builds, tools/build_variant.sh): every phase takes the barrier before its DAG loop, as round 2 did.
+#ifdef DVS_GATE_UPFRONT
+#define DVS_PHASE_GATE_INIT(pending) DVS_PHASE_GATE(pending)
+#else
+#define DVS_PHASE_GATE_INIT(pending) ((void)0)
+#endif
+#define DVS_PHASE_GATE(pending)      \
+    do {                             \
+        if (pending) {               \
+            dvs_lds_barrier();       \
+            pending = false;         \
+        }                            \
+    } while (0)
 
 // Epilogue: LayerNorm statistics of the new pre-sum; store tile + stats.
 __device__ __forceinline__ void dvs_store_pre(float* out_pre, float* out_stats, size_t dag, const f4 (&pre)[4], const Lane& L) {

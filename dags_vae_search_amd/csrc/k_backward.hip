@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_stack(BwdStackArgs s) {
             case DVS_PH_PROJ2: dvs_proj_bwd_phase<2, NW>(ph.u.p, smem, mine, first, next, more); break;
             default: dvs_proj_bwd_phase<3, NW>(ph.u.p, smem, mine, first, next, more); break;
         }
-        dvs_lds_barrier();   // publishes the next phase's staged images (tail commit); global tiles: same wave, same queue
+        // the barrier that publishes the next phase's staged images (tail commit) is taken by that phase itself, behind its
+        // first round's global loads (DVS_PHASE_GATE, dvs_kernels.h); global tiles: same wave, same queue
     }
 }
 
@@ -170,7 +171,18 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceArgs a) {
     }
     part[q][c] = s;
     __syncthreads();
-    if (q == 0 && in) *(f4*)(a.grads + i4) = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (q == 0) {                                  // wave 0: the 64 columns' totals, and (optionally) their sum of squares
+        const f4 tot = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        if (in) *(f4*)(a.grads + i4) = tot;
+        if (a.sqpart) {
+            // entries beyond P inside the last float4 are padding of the flat layout: written as computed, NOT counted
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += (in && i4 + e < a.P) ? tot[e] * tot[e] : 0.f;
+            ss = dvs_sum_wave(ss);                 // fixed order: bitwise reproducible
+            if (c == 0) a.sqpart[blockIdx.x] = ss;
+        }
+    }
 }
 
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st) {

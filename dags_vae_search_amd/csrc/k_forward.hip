@@ -461,12 +461,27 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
 #ifdef DVS_STAMPS
     unsigned long long ast_ = __builtin_amdgcn_s_memtime();
 #endif
+    bool gate = !stage_mine;                 // chained: the barrier that publishes this phase's images (DVS_PHASE_GATE)
+    DVS_PHASE_GATE_INIT(gate);
     dvs_stagger(L.wave);
-    for (int dag = dvs_bid() * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    // every wave of the workgroup runs the same number of rounds (the gate is a workgroup barrier): a wave beyond the batch
+    // in the last round skips its DAG inside the round
+    for (int base = dvs_bid() * L.nwaves; base < a.dims.B; base += gridDim.x * L.nwaves) {
+        const int dag = base + L.wave;
+        if (dag >= a.dims.B) {
+            DVS_PHASE_GATE(gate);
+            continue;
+        }
         ASTAMP(7);
-        f4 x[4], dummy[4];
+        f4 x[4], dummy[4], kvt[4];
         float rstd;
-        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+        {
+            DvsRawX rx;
+            dvs_load_x_issue(rx, a.xin, a.ln, dag, L);
+            if (a.kv) dvs_load_tile(kvt, a.kv, dag, L);
+            DVS_PHASE_GATE(gate);              // behind the round's global loads, ahead of the first LDS access
+            dvs_load_x_finish<false>(x, dummy, rstd, rx, a.ln, l.lg, l.lb, N, L);
+        }
 #ifdef DVS_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -475,9 +490,7 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
         {
             const Split3T xs = dvs_split3_T(x);
             if (a.kv) {
-                f4 kv[4];
-                dvs_load_tile(kv, a.kv, dag, L);
-                attn_qkv(q, k, v, xs, dvs_split3_T(kv), l, L);
+                attn_qkv(q, k, v, xs, dvs_split3_T(kvt), l, L);
             } else {
                 attn_qkv(q, k, v, xs, xs, l, L);
             }
@@ -525,6 +538,7 @@ __device__ __forceinline__ void dvs_attn_fwd_phase(const AttnArgs& a, char* smem
         dvs_store_pre(a.out_pre, a.out_stats, dag, y, L);
         ASTAMP(6);
     }
+    DVS_PHASE_GATE(gate);                    // a workgroup without a DAG
     DVS_STAMP(dvs_stamps_fwd, mine, 2);
     if (has_next) {
         // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
@@ -616,12 +630,24 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, 
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
     const int ntiles = a.dims.B * a.dims.NT;
+    bool gate = !stage_mine;                 // chained: the barrier that publishes this phase's images (DVS_PHASE_GATE)
+    DVS_PHASE_GATE_INIT(gate);
     dvs_stagger(L.wave);
-    for (int tile = dvs_bid() * L.nwaves + L.wave; tile < ntiles; tile += gridDim.x * L.nwaves) {
+    for (int base = dvs_bid() * L.nwaves; base < ntiles; base += gridDim.x * L.nwaves) {      // uniform round count (gate)
+        const int tile = base + L.wave;
+        if (tile >= ntiles) {
+            DVS_PHASE_GATE(gate);
+            continue;
+        }
         const DvsTile T = dvs_tile_of(tile, a.dims);
         f4 x[4], dummy[4];
         float rstd;
-        dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, T.Nl, L);
+        {
+            DvsRawX rx;
+            dvs_load_x_issue(rx, a.xin, a.ln, tile, L);
+            DVS_PHASE_GATE(gate);              // behind the round's global loads, ahead of the first LDS access
+            dvs_load_x_finish<false>(x, dummy, rstd, rx, a.ln, l.lg, l.lb, T.Nl, L);
+        }
         const uint32_t gdag = a.dims.dag_offset + T.dag;
         f4 h[4];
 #pragma unroll
@@ -660,6 +686,7 @@ __device__ __forceinline__ void dvs_ffn_fwd_phase(const FfnArgs& a, char* smem, 
             dvs_store_tile(a.out_norm, tile, xn, L);
         }
     }
+    DVS_PHASE_GATE(gate);                    // a workgroup without a tile
     DVS_STAMP(dvs_stamps_fwd, mine, 2);
     if (has_next) {
         // the older wave group fetches the next phase's images while it waits for the younger one (dvs_stage.h)
@@ -732,7 +759,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_stack(FwdStackArgs s) {
         const DvsPlanK next = plans + (more_img ? i + 1 : i);
         if (ph.kind == DVS_FPH_ATTN) dvs_attn_fwd_phase<NW>(ph.u.a, smem, mine, first, next, more_img);
         else dvs_ffn_fwd_phase(ph.u.f, smem, mine, first, next, more_img);
-        dvs_lds_barrier();               // publishes the next phase's staged images
+        // the barrier that publishes the next phase's staged images is taken by that phase, behind its first round's global
+        // loads (DVS_PHASE_GATE, dvs_kernels.h); the latent phase opens with __syncthreads
     }
 }
 

@@ -25,11 +25,16 @@ __global__ __launch_bounds__(256) void k_sqnorm_part(const float* g, int64_t n, 
 }
 // Every workgroup of k_adam re-derives the clip coefficient from the 256 partials (same tree, same order: bitwise the same
 // value everywhere) instead of waiting for a one-workgroup launch in between; workgroup 0 publishes it.
+// nparts: SQ_PARTS after k_sqnorm_part, dvs_sq_parts(n) when k_reduce_slabs left the partials (dvs_clip_adam_from_partials).
 __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
                                               float eps, float bc1, float bc2_sqrt, float max_norm, float* scratch,
-                                              const float* guard) {
+                                              const float* guard, int nparts) {
     __shared__ float part[256];
-    part[threadIdx.x] = scratch[2 + threadIdx.x];
+    {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 256) s += scratch[2 + i];      // fixed order
+        part[threadIdx.x] = s;
+    }
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
         if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
@@ -61,12 +66,13 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, float* g, flo
 }
 
 void dvs_launch_clip_adam(int64_t n, float* params, float* grads, float* m, float* v, float lr, float b1, float b2,
-                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, dvs_stream_t st) {
-    DVS_LAUNCH(k_sqnorm_part, dim3(SQ_PARTS), dim3(256), 0, st, (const float*)grads, n, scratch);
+                          float eps, int64_t step, float max_norm, float* scratch, const float* guard, bool have_partials,
+                          dvs_stream_t st) {
+    if (!have_partials) DVS_LAUNCH(k_sqnorm_part, dim3(SQ_PARTS), dim3(256), 0, st, (const float*)grads, n, scratch);
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
     DVS_LAUNCH(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, m, v, lr, b1, b2, eps,
-                       bc1, sqrtf(bc2), max_norm, scratch, guard);
+                       bc1, sqrtf(bc2), max_norm, scratch, guard, have_partials ? dvs_sq_parts(n) : SQ_PARTS);
 }
 
 // ---------------------------------------------------------------------------------------------------------

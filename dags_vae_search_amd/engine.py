@@ -171,10 +171,20 @@ class PaceEngine:
             _ptr(eps), _ptr(self._status), _ptr(losses), _ptr(mu), _ptr(logvar), host_tail.data_ptr(), int(host_seq) & 0xFFFFFF,
             _stream()), "dvs_loss_forward_notify")
 
-    def loss_backward(self, shape, params: torch.Tensor, gcoef: torch.Tensor, grads: torch.Tensor):
+    def loss_backward(self, shape, params: torch.Tensor, gcoef: torch.Tensor, grads: torch.Tensor,
+                      clip_scratch: Optional[torch.Tensor] = None):
+        """clip_scratch (device f32[CLIP_SCRATCH_FLOATS], the fused optimiser's scratch): dvs_loss_backward_sq — the kernel that
+        sums the gradient slabs also leaves the partial sums of squares the optimiser clips with (single-process steps only)."""
         ws = self.workspace(shape.batch, params.device)
         if grads.numel() < params.numel():
             raise ValueError("gradient buffer is smaller than the parameter buffer")
+        if clip_scratch is not None:
+            if clip_scratch.numel() < dl.CLIP_SCRATCH_FLOATS or clip_scratch.dtype != torch.float32:
+                raise ValueError(f"clip_scratch must hold {dl.CLIP_SCRATCH_FLOATS} float32 words")
+            dl.check(self.lib, self.lib.dvs_loss_backward_sq(
+                ctypes.byref(shape), _ptr(self._records), _nbytes(self._records), _ptr(params), params.numel(), _ptr(ws), _nbytes(ws),
+                _ptr(gcoef), _ptr(grads), _ptr(clip_scratch), _stream()), "dvs_loss_backward_sq")
+            return
         dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(shape), _ptr(self._records), _nbytes(self._records),
                                                       _ptr(params), params.numel(), _ptr(ws), _nbytes(ws), _ptr(gcoef),
                                                       _ptr(grads), _stream()), "dvs_loss_backward")
@@ -198,12 +208,15 @@ class PaceEngine:
                                                _ptr(state), _nbytes(state), _stream()), "dvs_decode")
         return state
 
-    def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard=None):
+    def clip_adam(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_norm, scratch, guard=None,
+                  from_partials: bool = False):
         """guard: optional device f32[2] = [non-finite flag, invalid-features flag]; the update is skipped on the device
-        when either is non-zero (include/dvs.h)."""
-        dl.check(self.lib, self.lib.dvs_clip_adam(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg),
-                                                  _ptr(exp_avg_sq), lr, beta1, beta2, eps, int(step), float(max_norm),
-                                                  _ptr(scratch), _ptr(guard), _stream()), "dvs_clip_adam")
+        when either is non-zero (include/dvs.h).  from_partials: `scratch` already holds the partial sums of squares of
+        `grads` (loss_backward(clip_scratch=scratch) wrote them): dvs_clip_adam_from_partials, one launch instead of two."""
+        fn = self.lib.dvs_clip_adam_from_partials if from_partials else self.lib.dvs_clip_adam
+        dl.check(self.lib, fn(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), lr, beta1, beta2, eps,
+                              int(step), float(max_norm), _ptr(scratch), _ptr(guard), _stream()),
+                 "dvs_clip_adam_from_partials" if from_partials else "dvs_clip_adam")
 
     def activation(self, batch: int, slot: int) -> torch.Tensor:
         out = torch.empty(batch, 16 * self.tiles, 64, dtype=torch.float32, device=self._ws.device)

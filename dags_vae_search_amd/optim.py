@@ -66,10 +66,21 @@ class Adam(torch.optim.Optimizer):
         if st.get("step", 0) > 0:
             st["step"] -= 1
 
+    def clip_scratch(self, device) -> torch.Tensor:
+        """The device scratch of the clip (DVS_CLIP_SCRATCH_FLOATS): [0] sum of squares, [1] clip coefficient, then partial sums.
+        ``train_batch`` hands it to the backward (``loss_and_grad(clip_scratch=...)``) so that the kernel that sums the gradient
+        slabs leaves the partials behind and ``step(from_partials=True)`` needs no pass over the gradient for its norm."""
+        if self._scratch is None or self._scratch.device != device:
+            from . import _lib as dl
+            self._scratch = torch.zeros(dl.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+        return self._scratch
+
     @torch.no_grad()
-    def step(self, closure=None, max_grad_norm: float = -1.0, guard: torch.Tensor = None):
+    def step(self, closure=None, max_grad_norm: float = -1.0, guard: torch.Tensor = None, from_partials: bool = False):
         """guard: optional device f32[2] [non-finite flag, invalid-features flag] of the step's forward; when either is
-        set the kernels leave parameters and moments untouched (``train_batch`` then calls ``step_skipped``)."""
+        set the kernels leave parameters and moments untouched (``train_batch`` then calls ``step_skipped``).
+        from_partials: the backward of THIS step wrote the gradient's partial sums of squares into ``clip_scratch`` (and
+        nothing has changed the gradient since — no all-reduce)."""
         if closure is not None:
             raise NotImplementedError("closure is not supported")
         model = self._model
@@ -77,13 +88,12 @@ class Adam(torch.optim.Optimizer):
             raise RuntimeError("call optimizer.attach(model) first")
         flat, grads = model.flat_params, model.bind_flat_grads()
         st = self._flat_state(flat)
-        if self._scratch is None or self._scratch.device != flat.device:
-            self._scratch = torch.zeros(320, dtype=torch.float32, device=flat.device)   # DVS_CLIP_SCRATCH_FLOATS
+        scratch = self.clip_scratch(flat.device)
         g = self.param_groups[0]
         st["step"] += 1
         model._eng().clip_adam(flat, grads, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
-                               float(g["betas"][1]), float(g["eps"]), st["step"], float(max_grad_norm), self._scratch,
-                               guard)
+                               float(g["betas"][1]), float(g["eps"]), st["step"], float(max_grad_norm), scratch,
+                               guard, from_partials=from_partials)
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients live in model.flat_grads and are overwritten by every backward: nothing to clear

@@ -484,7 +484,7 @@ class PaceVaeV3(nn.Module):
     # ---- fused step pieces used by train.train_batch / bench.py (no autograd graph) ----------------------------------
     def loss_and_grad(self, features: Dict, beta: float = 0.005, eps: Optional[torch.Tensor] = None,
                       packed: bool = False, defer_check: bool = False, early_read: bool = False,
-                      exchange=None) -> torch.Tensor:
+                      exchange=None, clip_scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Forward + backward straight into ``flat_grads`` (overwritten).  Returns the device tensor
         [total, recon, kld, non-finite flag, invalid-features flag]; nothing is synchronised."""
         eng = self._eng()
@@ -525,6 +525,6 @@ class PaceVaeV3(nn.Module):
         if not hasattr(self, "_gcoef") or self._gcoef.device != grads.device or self._gcoef_beta != beta:
             self._gcoef = torch.tensor([1.0, beta], dtype=torch.float32, device=grads.device)
             self._gcoef_beta = beta
-        eng.loss_backward(shape, self.flat_params, self._gcoef, grads)
+        eng.loss_backward(shape, self.flat_params, self._gcoef, grads, clip_scratch=clip_scratch)
         self.bind_flat_grads()            # host-only (re-points .grad views if an optimiser cleared them); GPU is busy
         return losses

@@ -172,7 +172,7 @@ class GPRegressionModel:
                                         sd["base_covar_module.base_kernel.raw_lengthscale"].reshape(())]).to(self.device)
         m = torch.zeros_like(flat)
         v = torch.zeros_like(flat)
-        scratch = torch.zeros(320, dtype=torch.float32, device=self.device)
+        scratch = torch.zeros(dl.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         hist = []
         for it in range(1, iterations + 1):

@@ -60,7 +60,10 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
             if ex is None or ex.group is not pg:
                 ex = model._dp_exchange = DpExchange(pg)
         # forward -> [side stream: ex.scalars] -> backward   (dist.DpExchange documents the order of the two collectives)
-        model.loss_and_grad(batch, defer_check=True, early_read=True, exchange=ex)
+        # single process: the kernel that sums the gradient slabs also leaves the partial sums of squares the clip needs
+        # (one launch less); data-parallel: the gradient changes in the all-reduce, its norm is taken afterwards
+        scratch = None if dp else optimizer.clip_scratch(model.flat_params.device)
+        model.loss_and_grad(batch, defer_check=True, early_read=True, exchange=ex, clip_scratch=scratch)
         guard = model._step_guard
         if dp:
             ex.gradient(model.flat_grads)
@@ -70,7 +73,7 @@ def train_batch(batch, model, optimizer, max_grad_norm=1.0, group=None):
         # loss_direct (pace.py:97-98), before backward / clip / step (main.py:111-116).  The optimiser kernels are already
         # enqueued when the host learns about it, so they carry the two flags as a device-side guard and skip the update
         # (data-parallel: the flags were all-reduced with the losses, every rank skips and raises alike).
-        optimizer.step(max_grad_norm=max_grad_norm, guard=guard)
+        optimizer.step(max_grad_norm=max_grad_norm, guard=guard, from_partials=not dp)
         host, status = model.read_step()                            # waits for the forward's notification / the side stream's copy only
         scalars = model._early_scalars                              # 0-d views of a device tensor owned by this step
         recon, kld = scalars[1], scalars[2]

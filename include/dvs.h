@@ -33,11 +33,11 @@
 extern "C" {
 #endif
 
-#define DVS_VERSION 201
+#define DVS_VERSION 202
 #define DVS_NUM_PARAMS 108
 #define DVS_RECORD_BYTES 96          /* one-tile path */
 #define DVS_RECORD_BYTES_WIDE 864    /* wide path; dvs_record_bytes(shape) returns the one that applies */
-#define DVS_CLIP_SCRATCH_FLOATS 320
+#define DVS_CLIP_SCRATCH_FLOATS 4096  /* 2 + partial sums of squares: 256 (dvs_clip_adam) or one per 256 parameters (dvs_loss_backward_sq) */
 #define DVS_DECODE_STATE_BYTES 440   /* sizeof(dvs_decode_state) */
 
 typedef struct dvs_shape {
@@ -129,6 +129,15 @@ int dvs_loss_forward_notify(const dvs_shape* s, const void* records, size_t reco
 int dvs_loss_backward(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
                       void* workspace, size_t workspace_bytes, const float* gcoef, float* grads, void* stream);
 
+/* dvs_loss_backward that also leaves the partial sums of squares of `grads` — one per 256 gradient entries, written by the
+ * kernel that sums the gradient slabs, in a fixed order — in clip_scratch[2 ..] (device f32[DVS_CLIP_SCRATCH_FLOATS], the
+ * `scratch` of the dvs_clip_adam_from_partials call that follows; NULL: plain dvs_loss_backward).  (ABI 202.)  For the
+ * single-process step only: clip_grad_norm_ (experiments/03_synthetic_12/main.py:115) needs the norm of the gradient the
+ * optimiser sees, so a data-parallel step, whose gradient changes in the all-reduce, uses dvs_loss_backward + dvs_clip_adam. */
+int dvs_loss_backward_sq(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
+                         void* workspace, size_t workspace_bytes, const float* gcoef, float* grads, float* clip_scratch,
+                         void* stream);
+
 /* PaceVaeV3.encode_direct (pace.py:1613-1641): mu, logvar device [B,32]. */
 int dvs_encode(const dvs_shape* s, const void* records, size_t records_bytes, const float* params, int64_t n_params,
                void* workspace, size_t workspace_bytes, float* mu, float* logvar, void* stream);
@@ -143,6 +152,12 @@ int dvs_encode(const dvs_shape* s, const void* records, size_t records_bytes, co
 int dvs_clip_adam(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
                   const float* guard, void* stream);
+
+/* The same update from the partial sums of squares dvs_loss_backward_sq left in scratch[2 ..] for exactly these n gradient
+ * entries (one launch instead of two: no pass over the gradient for its norm).  (ABI 202.) */
+int dvs_clip_adam_from_partials(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float lr,
+                                float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
+                                const float* guard, void* stream);
 
 /* One grown PACE graph of dvs_decode (vertex 0 = start, 1 = input, then the sampled vertices in order). */
 typedef struct dvs_decode_state {

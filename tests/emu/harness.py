@@ -59,12 +59,19 @@ class EmuModel:
                                                      None), "forward")
         return losses, mu, lv
 
-    def backward(self, g_recon=1.0, g_kld=0.005):
+    def backward(self, g_recon=1.0, g_kld=0.005, clip_scratch=None):
+        """clip_scratch (float32[CLIP_SCRATCH_FLOATS]): dvs_loss_backward_sq — the slab reduction also leaves the gradient's
+        partial sums of squares in clip_scratch[2:] for dvs_clip_adam_from_partials."""
         gcoef = np.asarray([g_recon, g_kld], np.float32)
         grads = np.full(self.P, np.nan, np.float32)
-        dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(self.shape), ptr(self.records), self.records.nbytes,
-                                                      ptr(self.flat), self.flat.size, ptr(self.ws), self.ws.nbytes,
-                                                      ptr(gcoef), ptr(grads), None), "backward")
+        if clip_scratch is not None:
+            dl.check(self.lib, self.lib.dvs_loss_backward_sq(ctypes.byref(self.shape), ptr(self.records), self.records.nbytes,
+                                                             ptr(self.flat), self.flat.size, ptr(self.ws), self.ws.nbytes,
+                                                             ptr(gcoef), ptr(grads), ptr(clip_scratch), None), "backward_sq")
+        else:
+            dl.check(self.lib, self.lib.dvs_loss_backward(ctypes.byref(self.shape), ptr(self.records), self.records.nbytes,
+                                                          ptr(self.flat), self.flat.size, ptr(self.ws), self.ws.nbytes,
+                                                          ptr(gcoef), ptr(grads), None), "backward")
         return {name: grads[off:off + int(np.prod(shp))].reshape(shp) for name, off, shp in self.table}, grads
 
     def activation(self, slot):

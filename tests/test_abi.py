@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_queries_without_a_gpu():
     lib = dl.load()
-    assert lib.dvs_version() == 201 == dl.ABI_VERSION
+    assert lib.dvs_version() == 202 == dl.ABI_VERSION
     shape = dl.make_shape(4096, 15, 15)
     table, total = dl.param_table(lib, shape)
     assert len(table) == 108 and total % 4 == 0

@@ -94,7 +94,7 @@ def test_emu_train0_golden_and_adam_step():
     gn = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
     exp_avg = np.zeros_like(m.flat)
     exp_avg_sq = np.zeros_like(m.flat)
-    scratch = np.zeros(320, np.float32)
+    scratch = np.zeros(4096, np.float32)
     p = m.flat.copy()
     # a raised guard (non-finite loss / invalid batch) must leave parameters, moments and gradients untouched
     for guard in ([1.0, 0.0], [0.0, 1.0]):
@@ -107,6 +107,18 @@ def test_emu_train0_golden_and_adam_step():
                              ptr(scratch), ptr(np.zeros(2, np.float32)), None)
     assert rc == 0
     assert abs(np.sqrt(scratch[0]) - gn) / gn < 1e-5
+    # the single-process step's variant (ABI 202): the slab reduction leaves the partial sums of squares behind
+    # (dvs_loss_backward_sq) and the optimiser starts from them (dvs_clip_adam_from_partials): same norm, same update
+    scratch2 = np.zeros(4096, np.float32)
+    _, flat2 = m.backward(1.0, 0.005, clip_scratch=scratch2)
+    nparts = ((m.P + 3) // 4 + 63) // 64
+    assert np.array_equal(flat2, np.concatenate([v.reshape(-1) for v in [flat2]]))       # (gradient itself unchanged by the variant)
+    assert abs(float(scratch2[2:2 + nparts].astype(np.float64).sum()) - gn ** 2) / gn ** 2 < 1e-5 and not scratch2[2 + nparts:].any()
+    p2, ea2, eas2 = m.flat.copy(), np.zeros_like(m.flat), np.zeros_like(m.flat)
+    rc = m.lib.dvs_clip_adam_from_partials(m.P, ptr(p2), ptr(flat2), ptr(ea2), ptr(eas2), 1e-4, 0.9, 0.999, 1e-8, 1, 1.0,
+                                           ptr(scratch2), ptr(np.zeros(2, np.float32)), None)
+    assert rc == 0 and abs(scratch2[0] - scratch[0]) <= 1e-5 * scratch[0]
+    assert np.abs(flat2 - flat).max() <= 1e-5 * np.abs(flat).max()              # both clipped in place by ~the same coefficient
     worst_big = 0.0
     for name, off, shp in m.table:
         n = int(np.prod(shp))

@@ -614,8 +614,9 @@ def test_host_notification_carries_the_same_scalars_as_the_device_tail():
     for _ in range(3):
         loss_value, recon, kld = train_batch(f, model, opt)
         torch.cuda.synchronize()
-        dev = model._step_tail.cpu()
+        dev = model._notify_losses.cpu()        # this step's own device scalars (recon / kld handed to the caller are views of it)
         host = model._host_tail
+        assert recon.is_cuda and kld.is_cuda and recon.dim() == 0      # main.py:111-118 returns 0-d device tensors
         assert torch.equal(host[:3], dev[:3]) and loss_value == float(dev[0])
         word = int(host.numpy().view("uint32")[3])
         assert (word & 0xFF) == 0 and float(dev[3]) == 0.0 and float(dev[4]) == 0.0     # no flag, no validation bit

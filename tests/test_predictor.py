@@ -93,7 +93,7 @@ def test_sgpr_training_trajectory_matches_the_oracles_adam_loop():
     lib = _emu_lib()
     flat = torch.zeros(M * D + 4)
     flat[:M * D] = X[:M].reshape(-1)
-    m, v, scratch = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(320)
+    m, v, scratch = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(4096)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     losses = []
     for it in range(1, iters + 1):

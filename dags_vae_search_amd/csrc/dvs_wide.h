@@ -12,6 +12,7 @@
 // Workgroups are persistent (grid = #CU) so that weight gradients keep the slab scheme of dvs_backward.h.
 #pragma once
 #include "dvs_backward.h"
+#include "dvs_bf16.h"
 
 constexpr int DVS_WNT = 3;                       // tiles per DAG at most
 constexpr int DVS_WSCR = DVS_WTOK * DVS_LD;      // floats of a [48][DVS_LD] row-major DAG tile set in LDS
@@ -151,7 +152,7 @@ __device__ __forceinline__ void embw_hidden(f4 (&e1)[4], const float* W1, const 
 
 constexpr int LOSSW_LDN2 = 36;
 struct LossWLds {
-    float *Wn1, *Wn2, *Wa, *Wb, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *V, *U, *dlm, *part, *scr;
+    float *Wn1, *Wn2, *Wa, *Wb, *bn1, *bn2, *be1, *w2, *b2, *lg, *lb, *V, *U, *dlm, *part, *scr, *pU, *pV;
 };
 __device__ __forceinline__ LossWLds lossw_lds(char* smem) {
     LossWLds l;
@@ -170,12 +171,14 @@ __device__ __forceinline__ LossWLds lossw_lds(char* smem) {
     l.U = l.V + DVS_WSCR;                       // [48][LD] shared (backward)
     l.dlm = l.U + DVS_WSCR;                     // [48][49] d logit matrix (backward)
     l.part = l.dlm + DVS_WTOK * (DVS_WTOK + 1); // 16
-    l.scr = l.part + 16;                        // 4 per-wave transpose tiles (backward)
+    l.scr = l.part + 16;                        // 4 per-wave transpose tiles (backward); then the parked h tiles of the DAG
+    l.pU = l.scr + 4 * DVS_SCR;                 // 4 blocks of 16 rows: parked dU tiles as bf16 [hi | lo] pairs (backward)
+    l.pV = l.pU + 4 * DVS_SCR;                  // likewise dV
     return l;
 }
-static inline size_t dvs_lossw_lds_floats() {
-    return 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128 + 2 * (size_t)DVS_WSCR +
-           DVS_WTOK * (DVS_WTOK + 1) + 16 + 4 * (size_t)DVS_SCR;
+static inline size_t dvs_lossw_lds_floats(bool backward = true) {       // forward: no parked dU / dV blocks
+    return (backward ? 0 : -8 * (ptrdiff_t)DVS_SCR) + 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128 + 2 * (size_t)DVS_WSCR +
+           DVS_WTOK * (DVS_WTOK + 1) + 16 + 12 * (size_t)DVS_SCR;
 }
 __device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a) {
     const int C = a.dims.C;
@@ -195,6 +198,11 @@ __device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a
     dvs_stage_vector(l.lb, a.ln.b, 64);
     for (int i = threadIdx.x; i < 2 * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
 }
+// backward only: the per-wave transpose tiles and the parked dU / dV blocks start as zeros (blocks of tiles the DAG does not
+// have — tile 3 always — are never written and are contracted as they are)
+__device__ __forceinline__ void lossw_zero_parks(const LossWLds& l) {
+    for (int i = threadIdx.x; i < 12 * DVS_SCR; i += blockDim.x) l.scr[i] = 0.f;
+}
 
 struct BuildWArgs {
     int B, N, C;
@@ -212,6 +220,50 @@ void dvs_launch_loss_fwd_w(const LossArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_embed_bwd_w(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
 void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st);
 void dvs_launch_loss_bwd_w(const LossArgs& a, int grid, dvs_stream_t st);
+
+// Cooperative weight gradient of ONE DAG of up to 3 tiles (dvs_coop_dw_bf, dvs_bf16.h, restated): acc (rows 16 (wave & 3) ..
+// of dW) += sum over the DAG's tiles of dY^T X and accb += column sums of dY, from the tiles parked as bf16 [hi | lo] pairs in
+// consecutive 16-row blocks (2 DVS_SCR bf16 each) of `abase` (dY) and `bbase` (X).  The K = 32 blocks are the tile pairs
+// (0, 1) and (2, 3); tiles >= NT (tile 3 always: it lies behind the buffers) are contracted against zeros.  Four waves share a
+// product: 16 accumulator registers per matrix instead of the 64 of a per-wave outer product.
+__device__ __forceinline__ void dvsw_coop_dw(f4 (&acc)[4], f4& accb, const dvs_bf16* abase, const dvs_bf16* bbase, int NT,
+                                                const Lane& L) {
+    const int ot = L.wave & 3;
+    constexpr int STRIDE = 2 * DVS_SCR;               // bf16 elements per 16-row block ([hi | lo] pair)
+    bf8 ones, zero;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ones[i] = (dvs_bf16)1.0f;
+        zero[i] = (dvs_bf16)0.0f;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int d = 2 * m + (L.g >> 1);
+        const bool real = d < NT;                     // tiles >= NT: never parked (tile 3: outside the buffers)
+        const int dc = real ? d : 0;
+        const dvs_bf16* ta = abase + dc * STRIDE;
+        const dvs_bf16* tb = bbase + dc * STRIDE;
+        bf8 ah = dvs_tr_frag(ta, 16 * ot, L), al = dvs_tr_frag(ta + DVS_PKB, 16 * ot, L);
+        ah = real ? ah : zero;
+        al = real ? al : zero;
+        accb = dvs_mfma_bf(al, ones, accb);
+        accb = dvs_mfma_bf(ah, ones, accb);
+        bf8 bh[4], bl[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            bh[it] = dvs_tr_frag(tb, 16 * it, L);
+            bl[it] = dvs_tr_frag(tb + DVS_PKB, 16 * it, L);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(al, bh[it], acc[it]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(ah, bl[it], acc[it]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] = dvs_mfma_bf(ah, bh[it], acc[it]);
+        DVS_SCHED_FENCE();
+    }
+}
+
 
 // one output tile (16 features ot) of a T-layout product, parked row-major: rows tok0 + r, columns 16 ot + 4g ..
 __device__ __forceinline__ void dvs_park_col(float* buf, int tok0, int ot, const f4& v, const Lane& L) {

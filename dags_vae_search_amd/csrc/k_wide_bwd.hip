@@ -10,10 +10,12 @@
 // Nothing but the sublayer input was saved: q, k, v and the probabilities are recomputed.
 //   stage 1  : x -> q,k,v (bf16x3 from the per-step images: waves 0..2NT-1 = (tile, half of the in-projection rows)) and
 //              dO^T = Wo^T dropout-mask(d pre) (the remaining waves, by output tile), parked in LDS   | barrier
-//   phase A  : thread (i, h): row statistics (lse, delta), O_i (for dWo), dq_i                     | barrier
-//   phase B  : thread (j, h): walks the queries i that may attend j; dk_j, dv_j in registers       | barrier
-//              dk, dv overwrite the K, V buffers                                                    | barrier
+//   core     : wave h = head h, fp32 MFMA over the NON-EMPTY (query tile, key tile) pairs of the DAG's mask, both score
+//              orientations (attnwb_core): row statistics, O (for dWo), dq; then dk, dv, which overwrite the head's own
+//              columns of the K, V buffers                                                            | barrier
 //   wave w   : stores dq, dk, dv tiles; dWo += dy(N)^T O(N) in MFMA accumulators                  | barrier
+// Round 2's core walked ancestor / descendant bit-rows with one lane per (token, head) on the VALU (35 k of the kernel's 48 k
+// cycles per DAG at n = 37, matrix pipe 5 % busy, 68 % of the wave cycles waiting: the walk is a chain of dependent LDS reads).
 // ---------------------------------------------------------------------------------------------------------
 struct AttnWBLds {
     dvs_bf16 *WoTh, *WoTl, *Winh, *Winl;     // bf16x3 pairs, in the order of the per-step block (dvs_wimg.h: WoutT, WinB)
@@ -45,7 +47,186 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
 }
 constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 12 * DVS_WTOK;
 
-// 8 waves: waves 0..NT-1 own the tiles (MFMA parts, dWo accumulators), all 8 share the items of phases A and B.
+
+// ---- MFMA core of the wide attention backward ----------------------------------------------------------------------------
+// Wave h owns head h: it touches ONLY the head's 8 feature columns c0 = 8h .. of the parked [48][DVS_LD] buffers, so the eight
+// waves need no synchronisation among themselves (dk / dv overwrite K / V in place).  Every MFMA operand of the head is loaded
+// from LDS, as two kinds of fragments per 16-token tile t:
+//   row[s]   = X[16t + r][c0 + 4s + g]          s = 0, 1     contraction over the head's 8 features (two K = 4 steps)
+//   col[reg] = X[16t + 4g + reg][c0 + (r & 7)]  reg = 0..3   contraction over the tile's 16 tokens (four K = 4 steps); A-operand
+//                                                            rows r >= 8 duplicate r - 8 and their result rows are ignored
+// (fragments are fetched where they are used).  For the in-place dk / dv: the K and V col fragments are read in the T pass only,
+// which ends before the S pass writes anything; the S pass reads the row fragments of key tile jt before it writes that tile.
+// Score tiles in both orientations come from the SAME registers with the operands swapped (dvs_device.h):
+//   T: S^T = K Q^T  -> reg <-> key j = 16jt + 4g + reg, lane r <-> query i      (row statistics in-lane + 2 swaps, dq, O)
+//   S: S   = Q K^T  -> reg <-> query i = 16it + 4g + reg, lane r <-> key j      (dk, dv)
+// and a D-layout register `reg` IS the B operand of contraction step `reg` (k = g <-> token 4g + reg).  Tile pairs whose
+// 16 x 16 block of the mask is empty — all pairs above the diagonal for DAGs in topological vertex order, more for sparse ones —
+// are skipped: `pairs` bit 3 it + jt.  Per pair: 12 MFMAs in each orientation.
+// fragments are fetched where they are used (cheap: 4-byte LDS reads; the kernel is register-bound, not LDS-bound)
+__device__ __forceinline__ void attnwb_row(float (&f)[2], const float* X, int t, int c0, const Lane& L) {
+    const float* p = X + (16 * t + L.r) * DVS_LD + c0 + L.g;
+    f[0] = p[0];
+    f[1] = p[4];
+}
+__device__ __forceinline__ f4 attnwb_col(const float* X, int t, int c0, const Lane& L) {
+    const float* p = X + (16 * t + 4 * L.g) * DVS_LD + c0 + (L.r & 7);
+    return f4{p[0], p[DVS_LD], p[2 * DVS_LD], p[3 * DVS_LD]};
+}
+// keep-factors {0, scale} of the probabilities' dropout for 4 elements: T orientation (query i = lane's, keys j0 .. j0 + 3,
+// j0 a multiple of 4: two draws), element index (h NTOK + i) NTOK + j as in k_attn_fwd_w
+__device__ __forceinline__ f4 attnwb_mask_T(uint32_t key, int h, int i, int j0, int NTOK, const DvsDrop& D) {
+    if (!D.on) return f4_splat(1.f);
+    const uint32_t p0 = (uint32_t)((h * NTOK + i) * NTOK + j0) >> 1;
+    const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+    f4 m;
+    m[0] = ((h0 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[1] = ((h0 >> 16) >= D.thr16) ? D.scale : 0.f;
+    m[2] = ((h1 & 0xFFFFu) >= D.thr16) ? D.scale : 0.f;
+    m[3] = ((h1 >> 16) >= D.thr16) ? D.scale : 0.f;
+    return m;
+}
+// S orientation: key j = lane's, queries i0 .. i0 + 3: one draw per element (the pair partner j ^ 1 lives in another lane)
+__device__ __forceinline__ f4 attnwb_mask_S(uint32_t key, int h, int i0, int j, int NTOK, const DvsDrop& D) {
+    if (!D.on) return f4_splat(1.f);
+    f4 m;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) m[reg] = dvs_dropout_elem(1.0f, key, (uint32_t)((h * NTOK + i0 + reg) * NTOK + j), D);
+    return m;
+}
+__device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, int NT, uint32_t kprob, const DvsDrop& D, float scale,
+                                            const Lane& L) {
+    const int c0 = 8 * h, NTOK = 16 * NT;
+    // non-empty tile pairs, from the DAG's 48 ancestor rows: lane i < 48 holds row i
+    uint32_t pairs = 0;
+    {
+        const uint64_t row = L.lane < DVS_WTOK ? l.al[L.lane] : 0ull;
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            const unsigned long long b = __ballot(((row >> (16 * jt)) & 0xFFFFull) != 0ull);
+#pragma unroll
+            for (int it = 0; it < DVS_WNT; ++it)
+                if ((b >> (16 * it)) & 0xFFFFull) pairs |= 1u << (3 * it + jt);
+        }
+    }
+    // ---- T orientation: per query tile ------------------------------------------------------------------------------------
+    for (int it = 0; it < NT; ++it) {
+        const int i = 16 * it + L.r;
+        const uint64_t row = l.al[i];
+        float fq[2], fg[2];
+        attnwb_row(fq, l.Q, it, c0, L);
+        attnwb_row(fg, l.DO, it, c0, L);
+        f4 sT[DVS_WNT], dpT[DVS_WNT];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            sT[jt] = dpT[jt] = f4_zero();
+            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            float fk[2], fv[2];
+            attnwb_row(fk, l.K, jt, c0, L);
+            attnwb_row(fv, l.V, jt, c0, L);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sT[jt] = dvs_mfma(fk[s], fq[s], sT[jt]);
+                dpT[jt] = dvs_mfma(fv[s], fg[s], dpT[jt]);
+            }
+            const uint32_t ok4 = (uint32_t)(row >> (16 * jt + 4 * L.g)) & 0xFu;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) m = ((ok4 >> reg) & 1u) ? fmaxf(m, sT[jt][reg]) : m;
+        }
+        m = dvs_max_g(m);
+        float den = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            const uint32_t ok4 = (uint32_t)(row >> (16 * jt + 4 * L.g)) & 0xFu;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                sT[jt][reg] = ((ok4 >> reg) & 1u) ? __expf(sT[jt][reg] - m) : 0.f;
+                den += sT[jt][reg];
+            }
+        }
+        den = dvs_sum_g(den);
+        const float rden = den > 0.f ? 1.0f / den : 0.f;              // padding queries have no keys: all-zero rows
+        float delta = 0.f;
+        f4 pmk[DVS_WNT];
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            pmk[jt] = f4_zero();
+            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            const f4 mk = attnwb_mask_T(kprob, h, i, 16 * jt + 4 * L.g, NTOK, D);
+            sT[jt] *= rden;                                           // P
+            dpT[jt] *= mk;                                            // d P' -> d P
+            pmk[jt] = sT[jt] * mk;                                    // P'
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) delta += sT[jt][reg] * dpT[jt][reg];
+        }
+        delta = dvs_sum_g(delta);
+        f4 dq = f4_zero(), o = f4_zero();
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            const f4 kc = attnwb_col(l.K, jt, c0, L), vc = attnwb_col(l.V, jt, c0, L);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float ds = sT[jt][reg] * (dpT[jt][reg] - delta);
+                dq = dvs_mfma(kc[reg], ds, dq);
+                o = dvs_mfma(vc[reg], pmk[jt][reg], o);
+            }
+        }
+        // D[row f = 4g + reg][col i = r]: the head's 8 features live in the lane groups g = 0, 1
+        if (L.g < 2) {
+            *(f4*)(l.DQ + i * DVS_LD + c0 + 4 * L.g) = dq * scale;
+            *(f4*)(l.O + i * DVS_LD + c0 + 4 * L.g) = o;
+        }
+        if (L.g == 0) {
+            l.lse[h * DVS_WTOK + i] = den > 0.f ? m + __logf(den) : 0.f;
+            l.delta[h * DVS_WTOK + i] = delta;
+        }
+    }
+    dvs_wave_sync();             // lse / delta: written by lanes g = 0, read by every lane of this wave below
+    // ---- S orientation: per key tile.  K / V fragments of tile jt first, its dk / dv rows (this head's columns) last: a later
+    //      key tile reads other rows, the T pass above is over ---------------------------------------------------------------
+    for (int jt = 0; jt < NT; ++jt) {
+        const int j = 16 * jt + L.r;
+        float fk[2], fv[2];
+        attnwb_row(fk, l.K, jt, c0, L);
+        attnwb_row(fv, l.V, jt, c0, L);
+        f4 dk = f4_zero(), dv = f4_zero();
+#pragma unroll
+        for (int it = 0; it < DVS_WNT; ++it) {
+            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            float fq[2], fg[2];
+            attnwb_row(fq, l.Q, it, c0, L);
+            attnwb_row(fg, l.DO, it, c0, L);
+            f4 s2 = f4_zero(), dp = f4_zero();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                s2 = dvs_mfma(fq[s], fk[s], s2);
+                dp = dvs_mfma(fg[s], fv[s], dp);
+            }
+            const int i0 = 16 * it + 4 * L.g;
+            const f4 lse4 = *(const f4*)(l.lse + h * DVS_WTOK + i0), del4 = *(const f4*)(l.delta + h * DVS_WTOK + i0);
+            const f4 mk = attnwb_mask_S(kprob, h, i0, j, NTOK, D);
+            const f4 qc = attnwb_col(l.Q, it, c0, L), gc = attnwb_col(l.DO, it, c0, L);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const bool ok = (l.al[i0 + reg] >> j) & 1ull;
+                const float p = ok ? __expf(s2[reg] - lse4[reg]) : 0.f;
+                const float ds = p * (dp[reg] * mk[reg] - del4[reg]);
+                dk = dvs_mfma(qc[reg], ds, dk);
+                dv = dvs_mfma(gc[reg], p * mk[reg], dv);
+            }
+        }
+        dvs_wave_sync();         // every lane's reads of this tile's K / V rows are done (in-order LDS queue of the wave)
+        if (L.g < 2) {
+            *(f4*)(l.K + j * DVS_LD + c0 + 4 * L.g) = dk;
+            *(f4*)(l.V + j * DVS_LD + c0 + 4 * L.g) = dv;
+        }
+    }
+}
+
+// 8 waves: waves 0..NT-1 own the tiles (stores, parked d y / O); waves 0..3 accumulate dWo; in the core wave h owns head h.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     const AttnWBLds l = attnwb_lds(smem);
@@ -66,12 +247,9 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     const int pw = L.wave >> 1, phalf = L.wave & 1;              // stage 1: (tile, half of the in-projection rows)
     const bool proj = L.wave < 2 * NT;
     const float scale = 0.35355339059327373f;
-    f4 aWo[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) aWo[i][j] = f4_zero();
-    float vbo = 0.f;
+    // d out_proj.weight / bias, cooperatively (dvs_backward.h): wave w < 4 accumulates rows 16w .. of dWo over the DAG's tiles —
+    // 16 accumulator registers per wave instead of 64 (all eight waves would carry them through the core)
+    f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, abo = f4_zero();
     for (int dag = blockIdx.x; dag < B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
@@ -79,12 +257,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
         if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {      // a wave without a tile prepares the rows
             const int i = threadIdx.x - 256;
-            const uint64_t row = i < N ? rec->allowed[i] : 0ull;
-            uint64_t e, o;
-            dvs_split_row(row, e, o);
-            l.al[i] = row;
-            l.al[DVS_WTOK + i] = e;
-            l.al[2 * DVS_WTOK + i] = o;
+            l.al[i] = i < N ? rec->allowed[i] : 0ull;
         }
         // ---- stage 1: all 8 waves, bf16x3 (q, k, v feed a softmax, dO is a gradient product: smooth, as in the one-tile backward) ----
         if (proj) {
@@ -141,136 +314,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             }
         }
         __syncthreads();
-        const DvsCoreItem it = dvs_core_item(N);          // (token, head[, half]) of this lane in phases A and B
-        const bool active = it.tok >= 0;
-        if (threadIdx.x >= 448 && threadIdx.x < 448 + DVS_WTOK) {       // descendant rows for phase B (rows are complete: barrier above)
-            const int j = threadIdx.x - 448;
-            uint64_t d = 0;
-            for (int i = 0; i < N; ++i) d |= ((l.al[i] >> j) & 1ull) << i;
-            uint64_t e, o;
-            dvs_split_row(d, e, o);
-            l.de[j] = d;
-            l.de[DVS_WTOK + j] = e;
-            l.de[2 * DVS_WTOK + j] = o;
-        }
-        // ---- phase A: (query i, head h) ---------------------------------------------------------------------------
-        // ONE pass over the (half) ancestor row, two keys per iteration (the walk is latency-bound): with e_j = exp(s_j - m)
-        // for a running maximum m, the sums den = S e, O' = S e mk v, D' = S e dp, A' = S e dp k, B' = S e k are rescaled
-        // whenever m grows; then p = e / den gives O = O'/den, delta = D'/den, dq = S p (dp - delta) k = (A' - delta B')/den.
-        {
-            const int i = active ? it.tok : 0, h = it.head, c0 = 8 * h;
-            const f4 q0 = *(const f4*)(l.Q + i * DVS_LD + c0), q1 = *(const f4*)(l.Q + i * DVS_LD + c0 + 4);
-            const f4 g0 = *(const f4*)(l.DO + i * DVS_LD + c0), g1 = *(const f4*)(l.DO + i * DVS_LD + c0 + 4);
-            float m = -3.0e38f, den = 0.f, dsum = 0.f;
-            f4 o0 = f4_zero(), o1 = f4_zero(), a0 = f4_zero(), a1 = f4_zero(), b0 = f4_zero(), b1 = f4_zero();
-            for (uint64_t mm = active ? l.al[(it.half + 1) * DVS_WTOK + i] : 0ull; mm;) {
-                const int j0 = dvs_ctz64(mm);
-                mm &= mm - 1;
-                const bool two = mm != 0;
-                const int j1 = two ? dvs_ctz64(mm) : j0;
-                mm &= mm - 1;
-                const float* k0p = l.K + j0 * DVS_LD + c0;
-                const float* k1p = l.K + j1 * DVS_LD + c0;
-                const float* v0p = l.V + j0 * DVS_LD + c0;
-                const float* v1p = l.V + j1 * DVS_LD + c0;
-                const float s0 = dvs_dot8(q0, q1, k0p);
-                const float s1 = two ? dvs_dot8(q0, q1, k1p) : -3.0e38f;
-                const float mn = fmaxf(m, fmaxf(s0, s1));
-                const float sc = __expf(m - mn);
-                const float e0 = __expf(s0 - mn), e1 = two ? __expf(s1 - mn) : 0.f;
-                const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j0), D) : 1.0f;
-                const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i) * NTOK + j1), D) : 1.0f;
-                const float dp0 = mk0 * dvs_dot8(g0, g1, v0p), dp1 = mk1 * dvs_dot8(g0, g1, v1p);
-                den = den * sc + (e0 + e1);
-                dsum = dsum * sc + (e0 * dp0 + e1 * dp1);
-                const float w0 = e0 * mk0, w1 = e1 * mk1, x0 = e0 * dp0, x1 = e1 * dp1;
-                o0 = o0 * sc + *(const f4*)v0p * w0 + *(const f4*)v1p * w1;
-                o1 = o1 * sc + *(const f4*)(v0p + 4) * w0 + *(const f4*)(v1p + 4) * w1;
-                a0 = a0 * sc + *(const f4*)k0p * x0 + *(const f4*)k1p * x1;
-                a1 = a1 * sc + *(const f4*)(k0p + 4) * x0 + *(const f4*)(k1p + 4) * x1;
-                b0 = b0 * sc + *(const f4*)k0p * e0 + *(const f4*)k1p * e1;
-                b1 = b1 * sc + *(const f4*)(k0p + 4) * e0 + *(const f4*)(k1p + 4) * e1;
-                m = mn;
-            }
-            // merge the two halves of a split row (all lanes execute the exchanges; whole-row lanes ignore them)
-            {
-                const float pm = dvs_pair_xchg(m), pden = dvs_pair_xchg(den), pds = dvs_pair_xchg(dsum);
-                const f4 po0 = dvs_pair_xchg(o0), po1 = dvs_pair_xchg(o1), pa0 = dvs_pair_xchg(a0), pa1 = dvs_pair_xchg(a1);
-                const f4 pb0 = dvs_pair_xchg(b0), pb1 = dvs_pair_xchg(b1);
-                if (it.half >= 0) {
-                    const float M = fmaxf(m, pm);
-                    const float fa = __expf(m - M), fb = __expf(pm - M);
-                    den = den * fa + pden * fb;
-                    dsum = dsum * fa + pds * fb;
-                    o0 = o0 * fa + po0 * fb;
-                    o1 = o1 * fa + po1 * fb;
-                    a0 = a0 * fa + pa0 * fb;
-                    a1 = a1 * fa + pa1 * fb;
-                    b0 = b0 * fa + pb0 * fb;
-                    b1 = b1 * fa + pb1 * fb;
-                    m = M;
-                }
-            }
-            if (active && it.half <= 0) {
-                const float rden = 1.0f / den;
-                const float delta = dsum * rden;
-                *(f4*)(l.O + i * DVS_LD + c0) = o0 * rden;
-                *(f4*)(l.O + i * DVS_LD + c0 + 4) = o1 * rden;
-                *(f4*)(l.DQ + i * DVS_LD + c0) = (a0 - b0 * delta) * (rden * scale);
-                *(f4*)(l.DQ + i * DVS_LD + c0 + 4) = (a1 - b1 * delta) * (rden * scale);
-                l.lse[h * DVS_WTOK + i] = m + __logf(den);
-                l.delta[h * DVS_WTOK + i] = delta;
-            }
-        }
-        __syncthreads();
-        // ---- phase B: (key j, head h), same lane layout (a token's DESCENDANT rows are long for early tokens, so the split
-        //      tokens here are the last ones by index too: the pair split still halves most of the long walks) ---------------
-        f4 dk0 = f4_zero(), dk1 = f4_zero(), dv0 = f4_zero(), dv1 = f4_zero();
-        {
-            const int j = active ? it.tok : 0, h = it.head, c0 = 8 * h;
-            const float* kp = l.K + j * DVS_LD + c0;
-            const float* vp = l.V + j * DVS_LD + c0;
-            for (uint64_t mm = active ? l.de[(it.half + 1) * DVS_WTOK + j] : 0ull; mm;) {   // queries that attend j, two per iteration
-                const int i0 = dvs_ctz64(mm);
-                mm &= mm - 1;
-                const bool two = mm != 0;
-                const int i1 = two ? dvs_ctz64(mm) : i0;
-                mm &= mm - 1;
-                const float* q0p = l.Q + i0 * DVS_LD + c0;
-                const float* q1p = l.Q + i1 * DVS_LD + c0;
-                const float* g0p = l.DO + i0 * DVS_LD + c0;
-                const float* g1p = l.DO + i1 * DVS_LD + c0;
-                // same operand order as phase A (q . k, dO . v): bitwise the same scores
-                const f4 qa0 = *(const f4*)q0p, qb0 = *(const f4*)(q0p + 4), qa1 = *(const f4*)q1p, qb1 = *(const f4*)(q1p + 4);
-                const f4 ga0 = *(const f4*)g0p, gb0 = *(const f4*)(g0p + 4), ga1 = *(const f4*)g1p, gb1 = *(const f4*)(g1p + 4);
-                const float p0 = __expf(dvs_dot8(qa0, qb0, kp) - l.lse[h * DVS_WTOK + i0]);
-                const float p1 = two ? __expf(dvs_dot8(qa1, qb1, kp) - l.lse[h * DVS_WTOK + i1]) : 0.f;
-                const float mk0 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i0) * NTOK + j), D) : 1.0f;
-                const float mk1 = D.on ? dvs_dropout_elem(1.0f, kprob, (uint32_t)((h * NTOK + i1) * NTOK + j), D) : 1.0f;
-                const float ds0 = p0 * (mk0 * dvs_dot8(ga0, gb0, vp) - l.delta[h * DVS_WTOK + i0]);
-                const float ds1 = p1 * (mk1 * dvs_dot8(ga1, gb1, vp) - l.delta[h * DVS_WTOK + i1]);
-                const float pm0 = p0 * mk0, pm1 = p1 * mk1;
-                dk0 += qa0 * ds0 + qa1 * ds1;
-                dk1 += qb0 * ds0 + qb1 * ds1;
-                dv0 += ga0 * pm0 + ga1 * pm1;
-                dv1 += gb0 * pm0 + gb1 * pm1;
-            }
-            const f4 pk0 = dvs_pair_xchg(dk0), pk1 = dvs_pair_xchg(dk1), pv0 = dvs_pair_xchg(dv0), pv1 = dvs_pair_xchg(dv1);
-            if (it.half >= 0) {       // fixed order (even half + odd half) on both lanes: bitwise reproducible
-                dk0 = it.half == 0 ? dk0 + pk0 : pk0 + dk0;
-                dk1 = it.half == 0 ? dk1 + pk1 : pk1 + dk1;
-                dv0 = it.half == 0 ? dv0 + pv0 : pv0 + dv0;
-                dv1 = it.half == 0 ? dv1 + pv1 : pv1 + dv1;
-            }
-        }
-        __syncthreads();
-        if (active && it.half <= 0) {
-            const int j = it.tok, c0 = 8 * it.head;
-            *(f4*)(l.K + j * DVS_LD + c0) = dk0;
-            *(f4*)(l.K + j * DVS_LD + c0 + 4) = dk1;
-            *(f4*)(l.V + j * DVS_LD + c0) = dv0;
-            *(f4*)(l.V + j * DVS_LD + c0 + 4) = dv1;
-        }
+        // ---- core: wave h = head h, on the matrix pipe (attnwb_core below) ----------------------------------------------
+        attnwb_core(l, L.wave, N, NT, kprob, D, scale, L);
         __syncthreads();
         if (has_tile) {
             const bool valid = L.r < Nl;
@@ -290,42 +335,42 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) g[t] = valid ? g[t] : f4_zero();
             dvs_store_tile(a.gv, tile, g, L);
-            // dWo += dy(N)^T (x) O(N); dbo += column sums of dy.  Q's rows of this tile are free now.
-            dvs_park_T(l.Q + tok0 * DVS_LD, dy, L);
+            // dWo += dy^T O, dbo += column sums of dy: both tiles parked as bf16 [hi | lo] pairs for the cooperative product
+            // below — d y over this tile's rows of Q (free now), O converted in place (a pair is exactly the 16 fp32 rows it replaces)
+            f4 o[4];
+            dvs_lds_T(o, l.O, tok0, L);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = valid ? o[t] : f4_zero();
             dvs_wave_sync();
-            vbo += dvs_colsum(l.Q + tok0 * DVS_LD, L);
-            f4 dyN[4], oN[4];
-            dvs_lds_N(dyN, l.Q, tok0, L);
-            dvs_lds_N(oN, l.O, tok0, L);
-            if (Nl < 16) {       // rows >= Nl of O were never written for this DAG: keep them out of the product
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) oN[t][kk] = (4 * L.g + kk < Nl) ? oN[t][kk] : 0.f;
-            }
-            dvs_outer_acc<4, 4>(aWo, dyN, oN);
+            dvs_park_bf((dvs_bf16*)(l.Q + tok0 * DVS_LD), dy, L);
+            dvs_park_bf((dvs_bf16*)(l.O + tok0 * DVS_LD), o, L);
         }
+        __syncthreads();
+        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)l.O, NT, L);
         __syncthreads();
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* region = (float*)smem;
-    dvs_stage_dw<4, 4>(region, aWo, L);
-    float* red = region + 2 * DVS_RED_MAT;            // 8 waves x 4096 staged floats precede it
-    red[L.wave * 64 + L.lane] = vbo;
+    float* red = (float*)smem;                        // [4 waves][64]
+    if (L.wave < 4) {
+        red[L.wave * 64 + L.lane] = 0.f;
+        dvs_wave_sync();
+        if (L.r == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) red[L.wave * 64 + 16 * L.wave + 4 * L.g + reg] = abo[reg];
+        }
+        dvs_coop_flush<4>(nullptr, slab + a.o_out_w, aWo, L);      // rows 16w .. of dWo straight from the accumulators
+    }
     __syncthreads();
-    dvs_flush_dw<4, 4>(region, slab + a.o_out_w, L);
     if (threadIdx.x < 64) {
         float s = 0.f;
-        for (int w = 0; w < 8; ++w) s += red[w * 64 + threadIdx.x];
+        for (int w = 0; w < 4; ++w) s += red[w * 64 + threadIdx.x];
         slab[a.o_out_b + threadIdx.x] = s;
     }
 }
 
 void dvs_launch_attn_bwd_w(const AttnBwdArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = ATTNWB_FLOATS * 4;
-    const size_t red = (2 * (size_t)DVS_RED_MAT + 512) * 4;
-    if (lds < red) lds = red;
+    const size_t lds = ATTNWB_FLOATS * 4;
     DVS_SET_LDS(k_attn_bwd_w, lds);
     DVS_LAUNCH(k_attn_bwd_w, dim3(grid), dim3(512), lds, st, a);
 }
@@ -337,6 +382,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
     DVS_DYN_LDS(smem);
     const LossWLds l = lossw_lds(smem);
     lossw_stage(l, a);
+    lossw_zero_parks(l);
     __syncthreads();
     const Lane L = dvs_lane();
     const int N = a.dims.N, C = a.dims.C, NT = a.dims.NT;
@@ -347,14 +393,15 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
     float* scr = l.scr + L.wave * DVS_SCR;
     const float b2 = l.b2[0];
     const float gr = a.gcoef[0];
-    f4 dWn1[2][4], dWn2[3][2], dWa[4][4], dWb[4][4], dbn1[2], dbn2[3], dbe1[4], dw2[4], dgam[4], dbet[4];
+    // the two 64 x 64 edge matrices cooperatively (dvsw_coop_dw): wave w accumulates rows 16w .. over the DAG's tiles — 16
+    // accumulator registers per matrix instead of 64 (round 2: 512 registers + 246 spilled, 636 bytes of scratch per lane);
+    // d edge0.bias rides along as the column sums of dV
+    f4 dWn1[2][4], dWn2[3][2], aWa[4], aWb[4], abU = f4_zero(), abV = f4_zero(), dbn1[2], dbn2[3], dw2[4], dgam[4], dbet[4];
     float db2 = 0.f;
+    dvs_bf16* const pU = (dvs_bf16*)l.pU;           // parked dU / dV tiles of the DAG, [hi | lo] pairs (4 blocks each: tile 3 zero)
+    dvs_bf16* const pV = (dvs_bf16*)l.pV;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dbe1[i] = dw2[i] = dgam[i] = dbet[i] = f4_zero();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dWa[i][j] = dWb[i][j] = f4_zero();
-    }
+    for (int i = 0; i < 4; ++i) dw2[i] = dgam[i] = dbet[i] = aWa[i] = aWb[i] = f4_zero();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         dbn1[i] = f4_zero();
@@ -504,13 +551,14 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) dV[t] = w2v[t] * sV[t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dbe1[t] += dV[t];
-            f4 dUN[4], dVN[4];
-            dvs_t2n<4>(dUN, dU, scr, L);
-            dvs_t2n<4>(dVN, dV, scr, L);
-            dvs_outer_acc<4, 4>(dWa, dUN, hN);
-            dvs_outer_acc<4, 4>(dWb, dVN, hN);
+            dvs_park_bf(pU + L.wave * 2 * DVS_SCR, dU, L);
+            dvs_park_bf(pV + L.wave * 2 * DVS_SCR, dV, L);
+            dvs_park_bf((dvs_bf16*)scr, h, L);                        // the wave's transpose tile is free by now
+        }
+        __syncthreads();
+        dvsw_coop_dw(aWa, abU, pU, (const dvs_bf16*)l.scr, NT, L);   // all four waves (wave 3 has no tile but owns rows 48..63)
+        dvsw_coop_dw(aWb, abV, pV, (const dvs_bf16*)l.scr, NT, L);
+        if (has_tile) {
             dvs_mat_Tt<4, 4>(dh, dU, l.Wa, DVS_LD, 0, L);
             dvs_mat_Tt<4, 4>(dh, dV, l.Wb, DVS_LD, 0, L);
             dvs_ln_bwd(dh, xhat, rstd, l.lg, dgam, dbet, L);
@@ -521,14 +569,13 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     {
-        float* rA = (float*)smem;
-        float* rB = rA + DVS_RED_MAT;
-        dvs_stage_dw<4, 4>(rA, dWa, L);
-        dvs_stage_dw<4, 4>(rB, dWb, L);
-        __syncthreads();
-        dvs_flush_dw<4, 4>(rA, slab + a.o_edge0_w, L, 64, 128);
-        dvs_flush_dw<4, 4>(rB, slab + a.o_edge0_w + 64, L, 64, 128);
-        __syncthreads();
+        // the edge matrices: rows 16w .. straight from wave w's accumulators (add_edge.0.weight is [64][128] = [Wa | Wb])
+        dvs_coop_flush<4>(nullptr, slab + a.o_edge0_w, aWa, L, false, false, 128);
+        dvs_coop_flush<4>(nullptr, slab + a.o_edge0_w + 64, aWb, L, false, false, 128);
+        if (L.r == 0) {          // d edge0.bias: wave w holds features 16w + 4g + reg (every column r the same)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) slab[a.o_edge0_b + 16 * L.wave + 4 * L.g + reg] = abV[reg];
+        }
         float* rN1 = (float*)smem;                      // 4 * 2048
         float* rN2 = rN1 + 4 * 2048;                    // 4 * 1536
         float* rv1 = rN2 + 4 * 1536;                    // dbn1: 4 * 32
@@ -540,7 +587,6 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
         dvs_stage_dw<3, 2>(rN2, dWn2, L);
         dvs_stage_vec<2>(rv1, dbn1, es, L);
         dvs_stage_vec<3>(rv2, dbn2, es, L);
-        dvs_stage_vec<4>(rv3, dbe1, es, L);
         dvs_stage_vec<4>(rv3 + DVS_RED_VEC, dw2, es, L);
         dvs_stage_vec<4>(rv3 + 2 * DVS_RED_VEC, dgam, es, L);
         dvs_stage_vec<4>(rv3 + 3 * DVS_RED_VEC, dbet, es, L);
@@ -551,7 +597,6 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
         dvs_flush_dw<3, 2>(rN2, slab + a.o_node2_w, L, C, 32);
         dvs_flush_vec<2>(rv1, slab + a.o_node0_b, L);
         dvs_flush_vec<3>(rv2, slab + a.o_node2_b, L, C);
-        dvs_flush_vec<4>(rv3, slab + a.o_edge0_b, L);
         dvs_flush_vec<4>(rv3 + DVS_RED_VEC, slab + a.o_edge2_w, L);
         dvs_flush_vec<4>(rv3 + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
         dvs_flush_vec<4>(rv3 + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
@@ -564,9 +609,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
 }
 
 void dvs_launch_loss_bwd_w(const LossArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = dvs_lossw_lds_floats() * 4;
-    const size_t red = (2 * (size_t)DVS_RED_MAT) * 4;
-    if (lds < red) lds = red;
+    const size_t lds = dvs_lossw_lds_floats() * 4;       // (the epilogue's staging areas are smaller than the DAG loop's layout)
     DVS_SET_LDS(k_loss_bwd_w, lds);
     DVS_LAUNCH(k_loss_bwd_w, dim3(grid), dim3(256), lds, st, a);
 }

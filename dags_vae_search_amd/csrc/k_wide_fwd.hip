@@ -400,6 +400,19 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         // All NT query tiles in one unrolled pass: their chains (LDS reads -> 2 + 4 dependent MFMAs per key tile -> shuffles
         // of the softmax) are independent, and one tile alone leaves the wave waiting on every link (measured: the serial
         // version was no faster than round 1's VALU walk).
+        // (query tile, key tile) pairs whose 16 x 16 block of the mask is empty are skipped — every pair above the diagonal for
+        // DAGs in topological vertex order, more for sparse ones (bit 3 it + jt; k_attn_bwd_w's core does the same)
+        uint32_t pairs = 0;
+        {
+            const uint64_t prow = L.lane < DVS_WTOK ? l.rows[L.lane] : 0ull;
+#pragma unroll
+            for (int jt = 0; jt < DVS_WNT; ++jt) {
+                const unsigned long long b = __ballot(((prow >> (16 * jt)) & 0xFFFFull) != 0ull);
+#pragma unroll
+                for (int it = 0; it < DVS_WNT; ++it)
+                    if ((b >> (16 * it)) & 0xFFFFull) pairs |= 1u << (3 * it + jt);
+            }
+        }
         float qb0[DVS_WNT], qb1[DVS_WNT];
         uint32_t okm[DVS_WNT][2];                                  // allowed bits of keys 4g.. + 16 jt: [0] jt = 0, 1; [1] jt = 2
         f4 s[DVS_WNT][DVS_WNT];
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
 #pragma unroll
             for (int it = 0; it < DVS_WNT; ++it) {
                 s[it][jt] = f4_zero();
-                if (it < NT && jt < NT) {
+                if ((pairs >> (3 * it + jt)) & 1u) {
                     s[it][jt] = dvs_mfma(ka0, qb0[it], s[it][jt]);
                     s[it][jt] = dvs_mfma(ka1, qb1[it], s[it][jt]);
                 }
@@ -431,12 +444,14 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         for (int it = 0; it < DVS_WNT; ++it) {
             m[it] = -3.0e38f;
 #pragma unroll
-            for (int jt = 0; jt < DVS_WNT; ++jt)
+            for (int jt = 0; jt < DVS_WNT; ++jt) {
+                if (!((pairs >> (3 * it + jt)) & 1u)) continue;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const bool ok = (okm[it][jt >> 1] >> (16 * (jt & 1) + reg)) & 1u;
                     m[it] = ok ? fmaxf(m[it], s[it][jt][reg]) : m[it];
                 }
+            }
         }
 #pragma unroll
         for (int it = 0; it < DVS_WNT; ++it) m[it] = dvs_max_x16(m[it]);
@@ -446,13 +461,15 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         for (int it = 0; it < DVS_WNT; ++it) {
             den[it] = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < DVS_WNT; ++jt)
+            for (int jt = 0; jt < DVS_WNT; ++jt) {
+                if (!((pairs >> (3 * it + jt)) & 1u)) continue;         // s stays zero
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const bool ok = (okm[it][jt >> 1] >> (16 * (jt & 1) + reg)) & 1u;
                     s[it][jt][reg] = ok ? __expf(s[it][jt][reg] - m[it]) : 0.f;
                     den[it] += s[it][jt][reg];
                 }
+            }
         }
 #pragma unroll
         for (int it = 0; it < DVS_WNT; ++it) den[it] = dvs_add_x16(den[it]);
@@ -466,8 +483,9 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
             const int i = 16 * it + L.r;
 #pragma unroll
             for (int jt = 0; jt < DVS_WNT; ++jt) {
+                if (!((pairs >> (3 * it + jt)) & 1u)) continue;
                 s[it][jt] *= rden;
-                if (D.on && it < NT && jt < NT) {   // element (h, i, j): index (h NTOK + i) NTOK + j, two per draw (dvs_dropout_elem)
+                if (D.on) {   // element (h, i, j): index (h NTOK + i) NTOK + j, two per draw (dvs_dropout_elem)
                     const uint32_t p0 = (uint32_t)((h * NTOK + i) * NTOK + 16 * jt + 4 * L.g) >> 1;
                     const uint32_t h0 = dvs_draw(kprob, p0), h1 = dvs_draw(kprob, p0 + 1);
                     s[it][jt][0] = ((h0 & 0xFFFFu) >= D.thr16) ? s[it][jt][0] * D.scale : 0.f;
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                     const float va = vp[kk * DVS_LD];
 #pragma unroll
                     for (int it = 0; it < DVS_WNT; ++it)
-                        if (it < NT) o[it] = dvs_mfma(va, s[it][jt][kk], o[it]);
+                        if ((pairs >> (3 * it + jt)) & 1u) o[it] = dvs_mfma(va, s[it][jt][kk], o[it]);
                 }
             }
         }
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
 }
 
 void dvs_launch_loss_fwd_w(const LossArgs& a, int grid, dvs_stream_t st) {
-    const size_t lds = dvs_lossw_lds_floats() * 4;
+    const size_t lds = dvs_lossw_lds_floats(false) * 4;
     DVS_SET_LDS(k_loss_fwd_w, lds);
     DVS_LAUNCH(k_loss_fwd_w, dim3(grid), dim3(256), lds, st, a);
 }

@@ -564,18 +564,22 @@ def test_fused_adam_state_dict_round_trip():
 
 
 def test_data_parallel_step_over_rccl_world1_equals_single_gpu_step(tmp_path):
-    """train_batch(group=True) had never run through RCCL.  One rank, backend nccl (= RCCL): the all-reduce of
-    [flat gradient | loss scalars], clip-after-reduce and the guarded Adam give bit-identical parameters and losses to the
-    single-GPU fused step."""
+    """train_batch(group=True) had never run through RCCL.  One rank, backend nccl (= RCCL): the two all-reduces
+    (five scalars behind the forward, flat gradient behind the backward), clip-after-reduce and the guarded Adam give
+    bit-identical parameters and losses to the single-GPU step taken through the same optimiser entry (norm from a pass over
+    the gradient); the fused single-GPU train_batch — whose norm comes from the slab reduction's partial sums, a different
+    summation order (ABI 202) — agrees to rounding."""
     import torch.distributed as dist
     from dags_vae_search_amd import optim as dopt
     from dags_vae_search_amd.train import train_batch
     cfg, params, graphs, z = load_golden("n12c12")
     a = build_model(cfg, params).train()
     b = build_model(cfg, params).train()
+    c = build_model(cfg, params).train()
     f = feats_for(a, graphs)
     oa = dopt.Adam(a.parameters(), lr=1e-3).attach(a)
     ob = dopt.Adam(b.parameters(), lr=1e-3).attach(b)
+    oc = dopt.Adam(c.parameters(), lr=1e-3).attach(c)
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
@@ -584,10 +588,16 @@ def test_data_parallel_step_over_rccl_world1_equals_single_gpu_step(tmp_path):
         for step in range(3):
             a.seed(step)
             b.seed(step)
+            c.seed(step)
             la = train_batch(f, a, oa)
             lb = train_batch(f, b, ob, group=True)
-            assert la[0] == lb[0] and la[1].item() == lb[1].item() and la[2].item() == lb[2].item()
-        assert torch.equal(a.flat_params, b.flat_params)
+            lc = c.loss_and_grad(f).clone()                    # forward + backward, then clip + Adam with the norm pass
+            oc.step(max_grad_norm=1.0)
+            assert lb[0] == lc[0].item() and lb[1].item() == lc[1].item() and lb[2].item() == lc[2].item()
+            assert rel(la[0], lb[0]) < 1e-6 and rel(la[2].item(), lb[2].item()) < 1e-6
+            assert lb[1].is_cuda and lb[1].dim() == 0
+        assert torch.equal(c.flat_params, b.flat_params)
+        assert (a.flat_params - b.flat_params).abs().max().item() < 1e-6
         bad = dict(f)
         bad["vertex_label_features"] = f["vertex_label_features"] * 0.5
         before = b.flat_params.clone()

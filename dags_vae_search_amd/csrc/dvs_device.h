@@ -134,6 +134,16 @@ __device__ __forceinline__ void dvs_stagger(int wave) {
 #define DVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// 1 / x as ONE v_rcp_f32 (1 ulp) instead of the IEEE-exact division sequence (v_div_scale, v_rcp, 4 x fma, v_div_fmas,
+// v_div_fixup: 12 instructions) for gradient terms whose parity bound is 2e-4 of the tensor maximum (sigmoid / softmax
+// denominators of the loss head's backward, which is vector-instruction bound)
+__device__ __forceinline__ float dvs_rcp(float x) {
+#ifdef DVS_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
 __device__ __forceinline__ f4 f4_zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f4 f4_splat(float v) { return f4{v, v, v, v}; }
 

@@ -43,14 +43,14 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
     float* dlm = scrU + DVS_SCR;      // [16][16] d logit matrix
     const float b2 = l.b2[0];
     const float gr = a.gcoef[0];
-    f4 dWn1[2][4], dWn2[1][2], dWa[4][4], dWb[4][4], dbn1[2], dbn2[1], dbe1[4], dw2[4], dgam[4], dbet[4];
+    // The two 64 x 64 edge matrices are accumulated COOPERATIVELY by the workgroup's four waves (one group of dvs_backward.h):
+    // every wave parks dU, dV and h of its DAG as bf16 [hi | lo] pairs, wave w accumulates rows 16w .. of dWa / dWb over the
+    // four DAGs on the bf16 pipe (dvs_coop_dw_bf) — 16 accumulator registers per matrix instead of 64 fp32-MFMA ones (round 2:
+    // 512 registers + 4 spilled, 20 bytes of scratch), and d edge0.bias rides along as the column sums of dV.
+    f4 dWn1[2][4], dWn2[1][2], aWa[4], aWb[4], abU = f4_zero(), abV = f4_zero(), dbn1[2], dbn2[1], dw2[4], dgam[4], dbet[4];
     float db2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dbe1[i] = dw2[i] = dgam[i] = dbet[i] = f4_zero();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dWa[i][j] = dWb[i][j] = f4_zero();
-    }
+    for (int i = 0; i < 4; ++i) dw2[i] = dgam[i] = dbet[i] = aWa[i] = aWb[i] = f4_zero();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         dbn1[i] = f4_zero();
@@ -60,10 +60,29 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
     }
     dbn2[0] = f4_zero();
     LBSTAMP(0);                  // staging + barrier + accumulator init
-    for (int dag = blockIdx.x * L.nwaves + L.wave; dag < a.dims.B; dag += gridDim.x * L.nwaves) {
+    const dvs_bf16* const slots = (const dvs_bf16*)l.scr;        // wave w's three tiles at w * 3 * DVS_SCR floats
+    constexpr int SLOT_STRIDE = 2 * 3 * DVS_SCR;                 // bf16 elements between the slots of two waves
+    // every wave runs the same number of rounds (workgroup barriers inside): a wave beyond the batch parks zero tiles
+    for (int base = blockIdx.x * L.nwaves; base < a.dims.B; base += gridDim.x * L.nwaves) {
+        const int dag = base + L.wave;
+        if (dag >= a.dims.B) {
+            const f4 z[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            dvs_park_bf((dvs_bf16*)scrV, z, L);
+            dvs_park_bf((dvs_bf16*)scrU, z, L);
+            dvs_park_bf((dvs_bf16*)dlm, z, L);
+            __syncthreads();
+            dvs_coop_dw_bf(aWa, abU, slots, slots + 2 * 2 * DVS_SCR, SLOT_STRIDE, L);
+            dvs_coop_dw_bf(aWb, abV, slots + 2 * DVS_SCR, slots + 2 * 2 * DVS_SCR, SLOT_STRIDE, L);
+            __syncthreads();
+            continue;
+        }
         f4 h[4], xhat[4];
         float rstd;
         dvs_load_x<true>(h, xhat, rstd, a.xin, a.ln, l.lg, l.lb, dag, N, L);
+        // touch the wave's NEXT tile (one dword per 64-byte piece: one load instruction): this kernel runs one wave per SIMD,
+        // nothing else hides the ~4 k cycles a cold tile load + LayerNorm statistics cost at the top of every round
+        const int nxt = dag + gridDim.x * L.nwaves;
+        const float touch = a.xin[(size_t)(nxt < a.dims.B ? nxt : dag) * DVS_TILE + L.lane * 16];
         const DvsRecord* rec = a.rec + dag;
         f4 hN[4];
         dvs_t2n<4>(hN, h, scrV, L);
@@ -93,13 +112,14 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
                 se += ex[reg];
             }
             se = dvs_sum_g(se);
+            const float rse = dvs_rcp(se);
             const int target = rec->label[(L.r + 1) & 15];
             const bool vt = L.r < N - 1;
             f4 dlg[1];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int c = 4 * L.g + reg;
-                dlg[0][reg] = (vt && c < C) ? gr * (ex[reg] / se - (c == target ? 1.f : 0.f)) : 0.f;
+                dlg[0][reg] = (vt && c < C) ? gr * (ex[reg] * rse - (c == target ? 1.f : 0.f)) : 0.f;
             }
             dbn2[0] += dlg[0];
             f4 dlgN[1], t1N[2];
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
                 const float logit = dvs_sum_g((ev[u][0] + ev[u][1]) + (ev[u][2] + ev[u][3])) + b2;
                 const bool pv = (L.r > jj[u]) && (L.r <= N - 2) && (u == 0 || has2);
                 const float truth = (float)((par >> (jj[u] + 1)) & 1u);
-                const float sg = 1.0f / (1.0f + __expf(-logit));
+                const float sg = dvs_rcp(1.0f + __expf(-logit));
                 dl[u] = pv ? gr * (sg - truth) : 0.f;
             }
 #pragma unroll
@@ -211,33 +231,38 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         }
         dvs_wave_sync();
         LBSTAMP(5);              // pass 2
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dbe1[t] += dV[t];
-        f4 dUN[4], dVN[4];
-        dvs_t2n<4>(dUN, dU, scrV, L);
-        dvs_t2n<4>(dVN, dV, scrV, L);
-        dvs_outer_acc<4, 4>(dWa, dUN, hN);
-        dvs_outer_acc<4, 4>(dWb, dVN, hN);
-        LBSTAMP(6);              // transposes + dWa, dWb outer products
+        // park dU, dV, h over the wave's three tiles (V, U and the d logit matrix are dead) and accumulate with the group
+        dvs_park_bf((dvs_bf16*)scrV, dU, L);
+        dvs_park_bf((dvs_bf16*)scrU, dV, L);
+        dvs_park_bf((dvs_bf16*)dlm, h, L);
+        __syncthreads();
+        dvs_coop_dw_bf(aWa, abU, slots, slots + 2 * 2 * DVS_SCR, SLOT_STRIDE, L);
+        dvs_coop_dw_bf(aWb, abV, slots + 2 * DVS_SCR, slots + 2 * 2 * DVS_SCR, SLOT_STRIDE, L);
+        __syncthreads();
+        LBSTAMP(6);              // parks + cooperative dWa, dWb
         dvs_matb_T<4>(dh, dvs_split_T(dU), l.WaT, l.WaT + DVS_IMG64, 0, L);       // d h += Wa^T dU + Wb^T dV (bf16x3: smooth)
         dvs_matb_T<4>(dh, dvs_split_T(dV), l.WbT, l.WbT + DVS_IMG64, 0, L);
         dvs_ln_bwd(dh, xhat, rstd, l.lg, dgam, dbet, L);
         dvs_store_tile(a.gout, dag, dh, L);
+#ifndef DVS_EMU
+        asm volatile("" ::"v"(touch));         // keeps the touch load alive without using its value
+#else
+        (void)touch;
+#endif
         LBSTAMP(7);              // d h products, LayerNorm backward, store
     }
     __syncthreads();
     LBSTAMP(8);                  // closing barrier
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
     {
-        // pass 1: the two 64x64 edge matrices; pass 2: node matrices + all vectors
-        float* rA = (float*)smem;
-        float* rB = rA + DVS_RED_MAT;
-        dvs_stage_dw<4, 4>(rA, dWa, L);
-        dvs_stage_dw<4, 4>(rB, dWb, L);
-        __syncthreads();
-        dvs_flush_dw<4, 4>(rA, slab + a.o_edge0_w, L, 64, 128);
-        dvs_flush_dw<4, 4>(rB, slab + a.o_edge0_w + 64, L, 64, 128);
-        __syncthreads();
+        // the edge matrices: rows 16w .. straight from wave w's accumulators (add_edge.0.weight is [64][128] = [Wa | Wb])
+        dvs_coop_flush<4>(nullptr, slab + a.o_edge0_w, aWa, L, false, false, 128);
+        dvs_coop_flush<4>(nullptr, slab + a.o_edge0_w + 64, aWb, L, false, false, 128);
+        if (L.r == 0) {          // d edge0.bias: wave w holds features 16w + 4g + reg (every column r the same)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) slab[a.o_edge0_b + 16 * L.wave + 4 * L.g + reg] = abV[reg];
+        }
+        // node matrices + the remaining vectors through LDS
         float* rN1 = (float*)smem;                      // 4 * 2048
         float* rN2 = rN1 + 4 * 2048;                    // 4 * 512
         float* rv = rN2 + 4 * 512;
@@ -246,7 +271,6 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         float* es = rv + 192 + 4 * DVS_RED_VEC + 16 + L.wave * DVS_SCR;
         dvs_stage_vec<2>(rv, dbn1, es, L);
         dvs_stage_vec<1>(rv + 128, dbn2, es, L);
-        dvs_stage_vec<4>(rv + 192, dbe1, es, L);
         dvs_stage_vec<4>(rv + 192 + DVS_RED_VEC, dw2, es, L);  // per-lane partials over pairs: summed over r like a bias
         dvs_stage_vec<4>(rv + 192 + 2 * DVS_RED_VEC, dgam, es, L);
         dvs_stage_vec<4>(rv + 192 + 3 * DVS_RED_VEC, dbet, es, L);
@@ -258,7 +282,6 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
         dvs_flush_dw<1, 2>(rN2, slab + a.o_node2_w, L, C, 32);
         dvs_flush_vec<2>(rv, slab + a.o_node0_b, L);
         dvs_flush_vec<1>(rv + 128, slab + a.o_node2_b, L, C);
-        dvs_flush_vec<4>(rv + 192, slab + a.o_edge0_b, L);
         dvs_flush_vec<4>(rv + 192 + DVS_RED_VEC, slab + a.o_edge2_w, L);
         dvs_flush_vec<4>(rv + 192 + 2 * DVS_RED_VEC, slab + a.o_ln_g, L);
         dvs_flush_vec<4>(rv + 192 + 3 * DVS_RED_VEC, slab + a.o_ln_b, L);
@@ -272,11 +295,9 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, DvsStagePlan plan)
 }
 
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
-    size_t lds = loss_lds_bytes(4, 3);
+    const size_t lds = loss_lds_bytes(4, 3);       // (the epilogue's staging areas are smaller than the DAG loop's layout)
     DvsStagePlan plan;
     loss_plan(plan, a);
-    const size_t red = (2 * DVS_RED_MAT) * 4;
-    if (lds < red) lds = red;
     DVS_SET_LDS(k_loss_bwd, lds);
     DVS_LAUNCH(k_loss_bwd, dim3(grid), dim3(256), lds, st, a, plan);
 }

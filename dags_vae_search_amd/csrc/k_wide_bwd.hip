@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
                         se += ex[ct][reg];
                     }
                 se = dvs_sum_g(se);
+                const float rse = dvs_rcp(se);
                 const int target = rec->label[tok + 1 < DVS_WTOK ? tok + 1 : 0];
                 const bool vt = tok < N - 1;
                 f4 dlg[3];
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int c = 16 * ct + 4 * L.g + reg;
-                        dlg[ct][reg] = (vt && c < C) ? gr * (ex[ct][reg] / se - (c == target ? 1.f : 0.f)) : 0.f;
+                        dlg[ct][reg] = (vt && c < C) ? gr * (ex[ct][reg] * rse - (c == target ? 1.f : 0.f)) : 0.f;
                     }
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) dbn2[ct] += dlg[ct];
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
                 const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
                 const bool pv = (tok > j) && (tok <= N - 2);
                 const float truth = (float)((par >> (j + 1)) & 1ull);
-                const float sg = 1.0f / (1.0f + __expf(-logit));
+                const float sg = dvs_rcp(1.0f + __expf(-logit));
                 const float dl = pv ? gr * (sg - truth) : 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {

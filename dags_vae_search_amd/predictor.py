@@ -151,11 +151,14 @@ class GPRegressionModel:
                 "covar_module.inducing_points": self.inducing_points.detach().cpu().clone()}
 
     def train_hyperparameters(self, iterations: int = 10000, lr: float = 0.01, log_every: int = 0, log=print,
-                              from_defaults: bool = True):
+                              from_defaults: bool = True, checkpoints=(), on_checkpoint=None):
         """The reference's training loop (gp.py:55-81 / main.py:329-365): `iterations` full-batch Adam(lr) steps on
         -ExactMarginalLogLikelihood, all on the device (module docstring).  ``from_defaults`` starts from gpytorch's
         initial values (raw parameters 0, constant 0, inducing points = train_x[:M]) like a freshly constructed reference
-        model; otherwise from the current hyper-parameters.  Returns [(iteration, loss)] at the logging points."""
+        model; otherwise from the current hyper-parameters.  Returns [(iteration, loss)] at the logging points.
+        ``checkpoints`` / ``on_checkpoint``: at these iteration counts the model's hyper-parameters are brought up to date and
+        ``on_checkpoint(iteration, self)`` is called INSIDE the one run (optimiser moments untouched) — how ``train_predictor``
+        gets the reference's MAE / MAPE-versus-iterations comments (gp.py:95-106) from a single 10 000-iteration run."""
         if self.device.type != "cuda":
             raise RuntimeError("dags_vae_search_amd.predictor trains only on the GPU (there is no CPU path)")
         X = self.train_x.to(torch.float32).contiguous()
@@ -183,11 +186,18 @@ class GPRegressionModel:
             if log_every and it % log_every == 0:
                 hist.append((it, float(loss)))
                 log("Iter %d/%d - Loss: %.3f" % (it, iterations, hist[-1][1]))
+            if on_checkpoint is not None and it in checkpoints:
+                self._adopt(flat, M, D)
+                on_checkpoint(it, self)
+        self._adopt(flat, M, D)
+        return hist
+
+    def _adopt(self, flat: torch.Tensor, M: int, D: int):
+        """hyper-parameters <- the flat training vector [inducing points | raw noise, constant, raw outputscale, raw lengthscale]"""
         rn, rc, ro, rl = flat[M * D:].tolist()
         self.noise, self.constant, self.outputscale, self.lengthscale = _sp(rn) + 1e-4, rc, _sp(ro), _sp(rl)
         self.inducing_points = flat[:M * D].view(M, D).clone()
         self._alpha = None
-        return hist
 
     def predict(self, x: torch.Tensor) -> torch.Tensor:
         """``model(x).mean`` of the reference for latent vectors x [B, dim] -> float64 [B], computed by k_gp_predict."""
@@ -206,3 +216,33 @@ class GPRegressionModel:
                                                    p(out), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                  "dvs_gp_predict")
         return out
+
+
+def train_predictor(X: torch.Tensor, y: torch.Tensor, iterations: int = 10000, lr: float = 0.01,
+                    checkpoints=(100, 1000, 2000, 5000, 10000), log=print, device="cuda"):
+    """The reference's predictor driver (experiments/01_bn_asia/main.py:315-393; src/predictors/gp.py:35-106): first 80 % of
+    the (vector, target) rows train, the rest test; SGPR with 500 inducing points = the first 500 training rows; ``iterations``
+    full-batch Adam(lr) steps on the negative exact marginal log-likelihood; then ``Test MAE`` / ``Test MAPE`` of the
+    predictive mean.  The reference's source carries those two figures after 100 / 1 000 / 2 000 / 5 000 iterations as
+    comments of separate runs (gp.py:95-106); here they come from ONE run through ``checkpoints``.
+    Returns (model, [{"iterations", "mae", "mape", "noise", "outputscale", "lengthscale", "constant"}]).
+    Parity against gpytorch itself is UNPINNED (gpytorch is absent; the reference ships neither predictions nor a loss curve)."""
+    import math as _m
+    n_train = int(_m.floor(0.8 * len(X)))                              # main.py:323
+    train_x, train_y = X[:n_train].contiguous(), y[:n_train].contiguous()
+    test_x, test_y = X[n_train:].contiguous(), y[n_train:].to(torch.float64)
+    model = GPRegressionModel(train_x, train_y, device=device)
+    rows = []
+
+    def report(it, m):
+        pred = m.predict(test_x).cpu()
+        err = (pred - test_y).abs()
+        rows.append({"iterations": it, "mae": float(err.mean()), "mape": float((err / test_y).mean()),     # main.py:373-374 (signed
+                     "noise": m.noise, "outputscale": m.outputscale, "lengthscale": m.lengthscale,         # denominator, as there)
+                     "constant": m.constant})
+        if log is not None:
+            log("%d\nTest MAE: %s\nTest MAPE: %s" % (it, rows[-1]["mae"], rows[-1]["mape"]))
+
+    cps = sorted({int(c) for c in checkpoints if 0 < int(c) <= iterations} | {iterations})
+    model.train_hyperparameters(iterations, lr=lr, checkpoints=cps, on_checkpoint=report)
+    return model, rows

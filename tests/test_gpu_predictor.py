@@ -70,3 +70,26 @@ def test_gp_hyperparameter_training_follows_the_reference_loop():
     pred = model.predict(x[ntr:]).cpu().numpy()
     mae = float(np.abs(pred - fix["y"][ntr:]).mean())
     assert abs(mae - 687.35) < 3.0, mae                 # oracle at 2000 iterations: 687.35; shipped model: 686.1
+
+
+def test_train_predictor_driver_reports_checkpoints_of_one_run():
+    """The reference's predictor driver shape (experiments/01_bn_asia/main.py:315-393): 80/20 split, SGPR on the first 80 %,
+    Test MAE / MAPE of the predictive mean — with the in-run checkpoints that stand for the reference's per-run comments
+    (gp.py:95-106).  A checkpoint must not disturb the run: the 60-iteration model equals the one trained without checkpoints,
+    and the 20-iteration row equals a separate 20-iteration run.  (Parity against gpytorch itself: unpinned.)"""
+    from dags_vae_search_amd.predictor import GPRegressionModel, train_predictor
+    fix = load_npz("asia_predictor.npz")
+    x, y = torch.from_numpy(fix["x"]), torch.from_numpy(fix["y"])
+    model, rows = train_predictor(x, y, iterations=60, checkpoints=(20, 60, 100), log=None)
+    assert [r["iterations"] for r in rows] == [20, 60]                       # 100 > iterations is dropped, the last one is always there
+    ntr = int(np.floor(0.8 * len(x)))
+    plain = GPRegressionModel(x[:ntr], y[:ntr])
+    plain.train_hyperparameters(iterations=60, lr=0.01)
+    assert plain.noise == model.noise and plain.lengthscale == model.lengthscale and plain.constant == model.constant
+    assert torch.equal(plain.inducing_points, model.inducing_points)
+    short = GPRegressionModel(x[:ntr], y[:ntr])
+    short.train_hyperparameters(iterations=20, lr=0.01)
+    err = (short.predict(x[ntr:]).cpu() - y[ntr:].double()).abs()
+    assert rows[0]["mae"] == pytest.approx(float(err.mean()), rel=1e-9)
+    assert rows[0]["mape"] == pytest.approx(float((err / y[ntr:].double()).mean()), rel=1e-9)
+    assert all(np.isfinite([r["mae"], r["mape"], r["noise"], r["lengthscale"]]).all() for r in rows)

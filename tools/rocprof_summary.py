@@ -14,8 +14,22 @@ import sqlite3
 import sys
 
 
+import re
+
+# template instances that differ only in their workgroup width (waves per workgroup: 8, or 4 in the narrow mapping of small
+# batches) share the name the per-kernel timing table of libdvs_hip.so and bench.py use
+_WIDTH_ONLY = re.compile(r"^(k_ffn_bwd|k_attn_bwd|k_attn_fwd)<\d+>$")
+_KEEP_FIRST = re.compile(r"^(k_bwd_stack|k_fwd_stack|k_proj_bwd)<(\d+), *\d+>$")
+
+
 def short(name):
     name = name.split("(")[0].replace("void ", "")
+    m = _KEEP_FIRST.match(name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = _WIDTH_ONLY.match(name)
+    if m:
+        return m.group(1)
     if name.startswith("_Z"):            # a name rocprofv3 could not demangle (_Float16-style types in the signature): _Z<len><name>...
         i = 2
         while i < len(name) and name[i].isdigit():
@@ -79,10 +93,12 @@ def pmc_csv(paths):
             if not k.startswith("k_"):
                 continue
             table[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[k] = (r["Workgroup_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
+            # no VGPR columns: rocprofv3's VGPR_Count is an allocation-granule figure (128 for a 253-register kernel, 256 for a
+            # 512-register one) — the truth is the code object's metadata, tools/kernel_resources.sh
+            meta[k] = (r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"])
             if r["Counter_Name"] not in counters:
                 counters.append(r["Counter_Name"])
-    print("kernel,dispatches,wg_size,vgpr,agpr,lds_bytes,scratch," + ",".join(counters))
+    print("kernel,dispatches,wg_size,lds_bytes,scratch," + ",".join(counters))
     for k, d in sorted(table.items(), key=lambda kv: -sum(kv[1].get(counters[0], [0]))):
         n = max(len(v) for v in d.values())
         print(k + f",{n}," + ",".join(meta[k]) + "," + ",".join(f"{sum(d[c]) / len(d[c]):.4e}" if d.get(c) else "" for c in counters))

@@ -100,13 +100,6 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
                                   c_int64, c_float, c_void_p, c_void_p, c_void_p]
     lib.dvs_clip_adam_from_partials.restype = c_int
     lib.dvs_clip_adam_from_partials.argtypes = lib.dvs_clip_adam.argtypes
-    lib.dvs_marker_create.restype = c_int
-    lib.dvs_marker_create.argtypes = [P(c_void_p)]
-    for fn in (lib.dvs_marker_record, lib.dvs_marker_wait):
-        fn.restype = c_int
-        fn.argtypes = [c_void_p, c_void_p]
-    lib.dvs_marker_destroy.restype = c_int
-    lib.dvs_marker_destroy.argtypes = [c_void_p]
     lib.dvs_profile_enable.restype = None
     lib.dvs_profile_enable.argtypes = [c_int]
     lib.dvs_profile_collect.restype = c_int
@@ -118,8 +111,7 @@ def bind(lib: ctypes.CDLL) -> ctypes.CDLL:
 
 EXPORTS = ["dvs_version", "dvs_last_error", "dvs_device_cus", "dvs_param_count", "dvs_param_table",
            "dvs_workspace_bytes", "dvs_record_bytes", "dvs_pack_features", "dvs_build_records", "dvs_loss_forward", "dvs_loss_forward_notify", "dvs_loss_backward", "dvs_loss_backward_sq", "dvs_encode", "dvs_decode", "dvs_bic_scores", "dvs_bic_parent_masks", "dvs_gp_predict", "dvs_gp_kernel", "dvs_gp_kernel_backward",
-           "dvs_clip_adam", "dvs_clip_adam_from_partials", "dvs_marker_create", "dvs_marker_record", "dvs_marker_wait",
-           "dvs_marker_destroy", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
+           "dvs_clip_adam", "dvs_clip_adam_from_partials", "dvs_debug_activation", "dvs_debug_launch", "dvs_profile_enable", "dvs_profile_collect"]
 
 
 def profile_collect(lib):

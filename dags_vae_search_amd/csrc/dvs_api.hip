@@ -1046,45 +1046,6 @@ extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, i
     return call_end("dvs_debug_activation");
 }
 
-// ---- a stream marker with DEVICE-scope release (include/dvs.h: dvs_marker_*) -----------------------------------------------
-// The data-parallel step records an event between the forward and the backward so that a side stream can all-reduce the five
-// loss scalars while the backward runs.  torch.cuda.Event is created with hipEventDisableTiming only: recording it releases to
-// SYSTEM scope (the dirty L2 lines of the forward are written back before the next kernel starts).  The side stream lives on
-// the same device: a device-scope release orders everything it needs.
-extern "C" int dvs_marker_create(void** marker) {
-    if (!marker) return fail(10, "dvs_marker_create: null pointer");
-#ifdef DVS_EMU
-    *marker = (void*)1;
-    return 0;
-#else
-    hipEvent_t ev = nullptr;
-    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
-    if (e != hipSuccess) return fail(20, hipGetErrorString(e));
-    *marker = (void*)ev;
-    return 0;
-#endif
-}
-extern "C" int dvs_marker_record(void* marker, void* stream) {
-#ifndef DVS_EMU
-    const hipError_t e = hipEventRecord((hipEvent_t)marker, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(20, hipGetErrorString(e));
-#endif
-    return 0;
-}
-extern "C" int dvs_marker_wait(void* marker, void* stream) {          // `stream` waits for the marker's last record
-#ifndef DVS_EMU
-    const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)marker, 0);
-    if (e != hipSuccess) return fail(20, hipGetErrorString(e));
-#endif
-    return 0;
-}
-extern "C" int dvs_marker_destroy(void* marker) {
-#ifndef DVS_EMU
-    if (marker) (void)hipEventDestroy((hipEvent_t)marker);
-#endif
-    return 0;
-}
-
 // Error-path test hook (include/dvs.h): an empty kernel through the product's launch macro.
 __global__ void k_debug_empty(int* sink) {
     DVS_DYN_LDS(smem);

@@ -21,7 +21,6 @@ import copy
 import math
 from typing import Dict, List, Optional, Tuple
 
-import ctypes
 import os
 
 import torch
@@ -333,25 +332,13 @@ class PaceVaeV3(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.flat_params.device)
             self._ev_tail = torch.cuda.Event()
-            # forward -> side stream hand-over: a marker with DEVICE-scope release (include/dvs.h: dvs_marker_*); a stock
-            # torch event releases to system scope when recorded, which stalls the backward's first kernel behind a write-back
-            # of the forward's dirty L2 lines.  DVS_DP_EVENT=torch: the stock event (A/B)
-            self._marker = None
-            if os.environ.get("DVS_DP_EVENT", "light") != "torch":
-                h = ctypes.c_void_p()
-                dl.check(self._eng().lib, self._eng().lib.dvs_marker_create(ctypes.byref(h)), "dvs_marker_create")
-                self._marker = h
-            else:
-                self._ev_forward = torch.cuda.Event()
-        if self._marker is not None:
-            lib = self._engine.lib
-            dl.check(lib, lib.dvs_marker_record(self._marker, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dvs_marker_record")
-            dl.check(lib, lib.dvs_marker_wait(self._marker, ctypes.c_void_p(self._side_stream.cuda_stream)), "dvs_marker_wait")
-        else:
-            self._ev_forward.record(torch.cuda.current_stream())
+            self._ev_forward = torch.cuda.Event()
+        # (a marker with DEVICE-scope release — hipEventDisableSystemFence through the C ABI — instead of this event was tried in
+        # round 3 on the world-1 RCCL path: 1.325 ms per step either way, same-call A/B; the ~12 us the single-GPU path saved by
+        # dropping its event are not the event's release scope)
+        self._ev_forward.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._side_stream):
-            if self._marker is None:
-                self._side_stream.wait_event(self._ev_forward)
+            self._side_stream.wait_event(self._ev_forward)
             src = self._step_losses
             if exchange is not None:
                 src = exchange.scalars(src)

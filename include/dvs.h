@@ -159,16 +159,6 @@ int dvs_clip_adam_from_partials(int64_t n, float* params, float* grads, float* e
                                 float beta1, float beta2, float adam_eps, int64_t step, float max_norm, float* scratch,
                                 const float* guard, void* stream);
 
-/* Stream marker with a DEVICE-scope release (hipEventDisableTiming | hipEventDisableSystemFence): what the data-parallel step
- * records between its forward and its backward so that a side stream of the SAME device can pick up the five loss scalars
- * (and all-reduce them) while the backward runs.  A default event releases to system scope on record — the forward's dirty L2
- * lines are written back before the backward's first kernel starts.  record: enqueue on `stream`; wait: make `stream` wait for
- * the marker's last record.  Not for host synchronisation and not across devices.  (ABI 202.) */
-int dvs_marker_create(void** marker);
-int dvs_marker_record(void* marker, void* stream);
-int dvs_marker_wait(void* marker, void* stream);
-int dvs_marker_destroy(void* marker);
-
 /* One grown PACE graph of dvs_decode (vertex 0 = start, 1 = input, then the sampled vertices in order). */
 typedef struct dvs_decode_state {
     uint64_t parents[48];   /* bit j of parents[i]: edge j -> i */

@@ -36,6 +36,20 @@ __device__ __forceinline__ float* dvs_bwd_epi(char* smem) { return (float*)(smem
 DVS_STAMP_DECL(dvs_stamps_bwd);
 #endif
 
+#ifndef DVS_TOUCH_MODE
+#define DVS_TOUCH_MODE 2
+#endif
+// -DDVS_TOUCH_ROUND (experiment): inside the DAG loop every wave touches the cold tile of its NEXT round at the top of the
+// current one (one load instruction, dvs_touch_first's idea applied within a phase)
+#ifdef DVS_TOUCH_ROUND
+#define DVS_ROUND_TOUCH(name, buf, tile_now, tile_next, ntiles, L) \
+    const float name = (buf)[(size_t)((tile_next) < (ntiles) ? (tile_next) : (tile_now)) * 1024 + (size_t)(L).lane * 16]
+#define DVS_ROUND_TOUCH_DONE(name) asm volatile("" ::"v"(name))
+#else
+#define DVS_ROUND_TOUCH(name, buf, tile_now, tile_next, ntiles, L) ((void)0)
+#define DVS_ROUND_TOUCH_DONE(name) ((void)0)
+#endif
+
 // ---- LDS layouts of the three phase kinds ----------------------------------------------------------------------------
 struct FfnBLds {
     // bf16x3 images (dvs_bf16.h) of W2^T and W1^T (d hidden, d x); W1 as the bf16x6 triple k_ffn_fwd uses: the hidden is
@@ -122,6 +136,7 @@ inline void ffnb_plan(DvsStagePlan& p, const FfnBwdArgs& a, char* smem) {
     dvs_plan_vec(p, smem, l.og, a.own.g, a.own_pre ? 64 : 0);
     dvs_plan_vec(p, smem, l.ob, a.own.b, a.own_pre ? 64 : 0);
     p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
+    dvs_plan_cold(p, a.xin, a.own_pre, a.dims.B * a.dims.NT);
     dvs_plan_seal(p);
 }
 inline void attnb_plan(DvsStagePlan& p, const AttnBwdArgs& a, char* smem) {
@@ -133,6 +148,7 @@ inline void attnb_plan(DvsStagePlan& p, const AttnBwdArgs& a, char* smem) {
     dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
     dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
     p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
+    dvs_plan_cold(p, a.xin, a.kv, a.dims.B * a.dims.NT);
     dvs_plan_seal(p);
 }
 inline void projb_plan(DvsStagePlan& p, const ProjBwdArgs& a, int nproj, char* smem) {
@@ -142,6 +158,7 @@ inline void projb_plan(DvsStagePlan& p, const ProjBwdArgs& a, int nproj, char* s
     dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
     dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
     p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
+    dvs_plan_cold(p, a.xin, nullptr, a.dims.B * a.dims.NT);
     dvs_plan_seal(p);
 }
 inline void dvs_bwd_plan(DvsStagePlan& p, const BwdPhase& ph, char* smem) {
@@ -213,6 +230,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         const int Nl = live ? N : 0;                       // a wave without a tile carries all-zero tiles
         f4 x[4], xhat[4], gp[4];
         float rstd;
+        DVS_ROUND_TOUCH(rt, a.xin, dg, dg + gridDim.x * NW, B, L);
         {
             DvsRawX rx;
             dvs_load_x_issue(rx, a.xin, a.ln, dg, L);      // the COLD load of the round (a saved forward activation; the gradient
@@ -289,11 +307,23 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
             dvs_ln_bwd_core(dx, xhat, rstd, l.lg, L);
         }
         if (live) dvs_store_tile(a.gout, dag, dx, L);
+        DVS_ROUND_TOUCH_DONE(rt);
     }
     DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    // every wave touches its first tiles of the next phase (dvs_stage.h) — BEHIND the older group's image prefetch: ahead of it
+    // the cold reads delay the issue of the 73 KB of image loads, which for the short phases sits on the critical path
+    // (DVS_TOUCH_MODE: 0 none, 1 ahead of the prefetch, 2 behind it; A/B builds)
+#if DVS_TOUCH_MODE == 1
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#endif
     DvsBwdTail tail;
     dvs_tail_issue(tail, next, has_next);
+#if DVS_TOUCH_MODE == 2
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#elif DVS_TOUCH_MODE == 0
+    const DvsTouch touch = {{0.f, 0.f}};
+#endif
     DVS_STAMP(dvs_stamps_bwd, mine, 3);
     dvs_lds_barrier();
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
@@ -330,6 +360,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
     dvs_tail_commit(tail, next, has_next, smem);       // below DVS_BWD_EPI_FLOOR: does not touch what the flush still reads
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
+    dvs_touch_done(touch);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -383,6 +414,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
         const int Nl = live ? dvs_tile_of((int)dg, a.dims).Nl : 0;
         f4 x[4], xhat[4], dx[4];
         float rstd;
+        DVS_ROUND_TOUCH(rt, a.xin, dg, dg + gridDim.x * NW, B, L);
         {
             DvsRawX rx;
             dvs_load_x_issue(rx, a.xin, a.ln, dg, L);      // the cold load of the round
@@ -432,11 +464,23 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
             }
             dvs_store_tile(a.gout, dag, dx, L);
         }
+        DVS_ROUND_TOUCH_DONE(rt);
     }
     DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    // every wave touches its first tiles of the next phase (dvs_stage.h) — BEHIND the older group's image prefetch: ahead of it
+    // the cold reads delay the issue of the 73 KB of image loads, which for the short phases sits on the critical path
+    // (DVS_TOUCH_MODE: 0 none, 1 ahead of the prefetch, 2 behind it; A/B builds)
+#if DVS_TOUCH_MODE == 1
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#endif
     DvsBwdTail tail;
     dvs_tail_issue(tail, next, has_next);
+#if DVS_TOUCH_MODE == 2
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#elif DVS_TOUCH_MODE == 0
+    const DvsTouch touch = {{0.f, 0.f}};
+#endif
     DVS_STAMP(dvs_stamps_bwd, mine, 3);
     dvs_lds_barrier();
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
@@ -471,6 +515,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
     dvs_tail_commit(tail, next, has_next, smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
+    dvs_touch_done(touch);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -790,8 +835,19 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         dvs_group_barrier(G, L);
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
+    // every wave touches its first tiles of the next phase (dvs_stage.h) — BEHIND the older group's image prefetch: ahead of it
+    // the cold reads delay the issue of the 73 KB of image loads, which for the short phases sits on the critical path
+    // (DVS_TOUCH_MODE: 0 none, 1 ahead of the prefetch, 2 behind it; A/B builds)
+#if DVS_TOUCH_MODE == 1
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#endif
     DvsBwdTail tail;
     dvs_tail_issue(tail, next, has_next);
+#if DVS_TOUCH_MODE == 2
+    const DvsTouch touch = dvs_touch_first(next, has_next, NW, L.wave, L.lane);
+#elif DVS_TOUCH_MODE == 0
+    const DvsTouch touch = {{0.f, 0.f}};
+#endif
     DVS_STAMP(dvs_stamps_bwd, mine, 3);
     dvs_lds_barrier();
     DVS_STAMP(dvs_stamps_bwd, mine, 4);
@@ -815,5 +871,6 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     DVS_STAMP(dvs_stamps_bwd, mine, 5);
     dvs_tail_commit(tail, next, has_next, smem);
     DVS_STAMP(dvs_stamps_bwd, mine, 6);
+    dvs_touch_done(touch);
 }
 

@@ -26,13 +26,18 @@ struct DvsStagePlan {
     // small vectors (biases, LayerNorm parameters), cut into units of <= 64 floats: unit j = elements vbase[j] .. vbase[j] + 63
     // of the vector at vsrc[j] (vlen[j] elements in all, 0: unused unit) -> LDS floats vdst[j] + vbase[j] ..
     const float* vsrc[DVS_PLAN_VECS];
-    int vdst[DVS_PLAN_VECS];
-    int vbase[DVS_PLAN_VECS];
-    int vlen[DVS_PLAN_VECS];
+    unsigned short vdst[DVS_PLAN_VECS];      // (16-bit: LDS float indices stay below 40 960; the 9-phase tables must fit the
+    unsigned short vbase[DVS_PLAN_VECS];     // 4 KB kernel-argument block)
+    unsigned short vlen[DVS_PLAN_VECS];
     int vperm;                         // bit j: unit j is read through dvs_pi (attention slot order)
     int nvec;
     int zero_int;                      // LDS int index of two group-barrier counters to clear, or -1
     int phase;                         // index of the phase inside its chained launch (diagnostic stamps, tools/phase_stamps.py)
+    // COLD inputs of the phase's DAG loop: tile buffers last written a whole pass ago (saved forward activations, the decoder
+    // memory) — as opposed to the tiles the same wave wrote one phase earlier.  The PREVIOUS phase's tail touches the first
+    // round's tiles of these (dvs_touch_first) so that every wave of the chip does not open the phase with the same HBM burst.
+    const float* cold[2];              // unused entries repeat a valid pointer (unconditional loads)
+    int cold_tiles;                    // tiles in each buffer (B * NT); 0: nothing to touch
 };
 
 // Diagnostic build only (make stamps -> libdvs_hip_stamps.so, never shipped or loaded by the package): lane 0 of every
@@ -73,6 +78,13 @@ DVS_HD inline void dvs_plan_clear(DvsStagePlan& p) {
     p.nvec = 0;
     p.vperm = 0;
     p.zero_int = -1;
+    p.cold[0] = p.cold[1] = nullptr;
+    p.cold_tiles = 0;
+}
+DVS_HD inline void dvs_plan_cold(DvsStagePlan& p, const float* a, const float* b, int tiles) {
+    p.cold[0] = a ? a : b;
+    p.cold[1] = b ? b : a;
+    p.cold_tiles = (a || b) ? tiles : 0;
 }
 DVS_HD inline void dvs_plan_seg(DvsStagePlan& p, const char* smem, const void* lds_dst, const void* src, int n_bf16) {
     p.src = (const f4*)src;
@@ -87,9 +99,9 @@ DVS_HD inline void dvs_plan_vec(DvsStagePlan& p, const char* smem, const float* 
             return;
         }
         p.vsrc[p.nvec] = src;
-        p.vdst[p.nvec] = (int)(((const char*)lds_dst - smem) >> 2);
-        p.vbase[p.nvec] = base;
-        p.vlen[p.nvec] = n;
+        p.vdst[p.nvec] = (unsigned short)(((const char*)lds_dst - smem) >> 2);
+        p.vbase[p.nvec] = (unsigned short)base;
+        p.vlen[p.nvec] = (unsigned short)n;
         if (perm) p.vperm |= 1 << p.nvec;
         ++p.nvec;
     }
@@ -227,6 +239,36 @@ __device__ __forceinline__ void dvs_prefetch_commit(const DvsPrefetch<NCH>& pf, 
     }
     if (p->zero_int >= 0 && tid < 2) ((int*)smem)[p->zero_int + tid] = 0;
 }
+// Touch the tiles this wave will load first in the NEXT phase (round 0 of its DAG loop: tile bid * nw + wave) from the phase's
+// cold buffers: one dword per 64-byte piece of the 4 KB tile = ONE load instruction per tile, whose only purpose is to start the
+// line fills while the tail of the current phase runs (barriers, gradient flush, image commit: 5-8 k cycles).  Without it all
+// 2 048 waves of the chip open a backward phase with the same ~16 MB burst of cold reads and both waves of every SIMD sit in it
+// (the first DAG round of the backward chains costs ~0.1 ms per step more than a later round at B = 4096).
+// The values are kept alive until dvs_touch_done at the end of the phase function — a register each, never used.
+struct DvsTouch {
+    float v[2];
+};
+template <class PP>
+__device__ __forceinline__ DvsTouch dvs_touch_first(PP next, bool has_next, int nw, int wave, int lane) {
+    DvsTouch t;
+    t.v[0] = t.v[1] = 0.f;
+    if (has_next && next->cold_tiles > 0) {
+        int tile = dvs_bid() * nw + wave;
+        tile = tile < next->cold_tiles ? tile : 0;
+        const size_t off = (size_t)tile * 1024 + (size_t)lane * 16;
+        t.v[0] = next->cold[0][off];
+        t.v[1] = next->cold[1][off];
+    }
+    return t;
+}
+__device__ __forceinline__ void dvs_touch_done(const DvsTouch& t) {
+#ifndef DVS_EMU
+    asm volatile("" ::"v"(t.v[0]), "v"(t.v[1]));
+#else
+    (void)t;
+#endif
+}
+
 // Stage a plan right away (first phase of a launch, per-phase launches): all loads in flight, then the stores.  The plan
 // must fit NCH chunks per thread at this workgroup size (a 1024-thread workgroup needs half as many).
 template <int NCH, class PP>

@@ -82,8 +82,8 @@ def algo_flops_per_dag(N: int, C: int):
 STACK_PHASES = {   # what one launch of a chained kernel walks (csrc/k_forward.hip, k_backward.hip)
     "k_fwd_stack<0>": "encoder forward: 3 x (attention, FFN)",
     "k_fwd_stack<1>": "decoder forward: 3 x (self-attention, cross-attention, FFN)",
-    "k_bwd_stack<0>": "decoder backward, 9 of its 18 phases per launch: 3 x (FFN, cross-attention core, q projection, "
-                      "k/v projections, self-attention core, q/k/v projections)",
+    "k_bwd_stack<0>": "decoder backward, its 15 phases in two launches (9 + 6; the figure is the per-launch average): 3 x (FFN, "
+                      "cross-attention core, q | k,v projections as one split phase, self-attention core, q/k/v projections)",
     "k_bwd_stack<1>": "encoder backward: 3 x (FFN, attention core, q/k/v projections)",
 }
 

@@ -37,6 +37,12 @@ struct ProjBwdArgs {             // backward of 1..3 stacked 64->64 projections 
     float* gout;                 // result: d(pre of producer) / d(X)
     int accumulate_out;          // 1: gout += (decoder memory gradient over layers)
     int slot_order;              // 1: the projections' output rows are in attention slot order (dvs_pi)
+    // split mode (3 projections, cross-attention: q of one input, k and v of another — one phase instead of two): projection 0
+    // is the backward of xin (with ln / gres / gout as above), projections 1, 2 that of xin2 (used as is), whose gradient goes to
+    // gout2 (+= when accumulate_out2).  xin2 == nullptr: all projections share xin.
+    const float* xin2;
+    float* gout2;
+    int accumulate_out2;
     float* slab;
     int64_t P;
     int64_t o_w, o_b, o_ln_g, o_ln_b;

@@ -158,7 +158,7 @@ inline void projb_plan(DvsStagePlan& p, const ProjBwdArgs& a, int nproj, char* s
     dvs_plan_vec(p, smem, l.lg, a.ln.g, a.ln.stats ? 64 : 0);
     dvs_plan_vec(p, smem, l.lb, a.ln.b, a.ln.stats ? 64 : 0);
     p.zero_int = (int)(((const char*)l.gcount - smem) >> 2);
-    dvs_plan_cold(p, a.xin, nullptr, a.dims.B * a.dims.NT);
+    dvs_plan_cold(p, a.xin, a.xin2, a.dims.B * a.dims.NT);
     dvs_plan_seal(p);
 }
 inline void dvs_bwd_plan(DvsStagePlan& p, const BwdPhase& ph, char* smem) {
@@ -429,16 +429,22 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
             dvs_zero_rows(dx, Nl, L);
         }
         dvs_park_bf(myB, x, L);
+        const bool split = NPROJ == 3 && a.xin2 != nullptr;      // uniform: q of X, then k and v of X2 (dvs_backward.h)
+        // d X += W_p^T dY_p, dW_p += dY_p^T X over projections p0 .. p1 - 1 against the tile parked in myB
+        auto run = [&](int p0, int p1, f4 (&acc_dx)[4]) {
 #pragma unroll
-        for (int p = 0; p < NPROJ; ++p) {
-            dvs_bf16* mine = (p & 1) ? myA1 : myA0;
-            f4 dy[4];
-            dvs_load_grad(dy, a.gy[p], dg, Nl, L);
-            dvs_park_bf(mine, dy, L);
-            dvs_group_barrier(G, L);
-            dvs_coop_dw_bf(aW[p], ab[p], slots + (p & 1) * 2 * DVS_PKB, slots + 4 * DVS_PKB, DVS_PROJB_SLOT, L);
-            dvs_matb_T<4>(dx, dvs_split_T(dy), WT + p * 2 * DVS_IMG64, WT + p * 2 * DVS_IMG64 + DVS_IMG64, 0, L);
-        }
+            for (int p = 0; p < NPROJ; ++p) {
+                if (p < p0 || p >= p1) continue;
+                dvs_bf16* mine = (p & 1) ? myA1 : myA0;
+                f4 dy[4];
+                dvs_load_grad(dy, a.gy[p], dg, Nl, L);
+                dvs_park_bf(mine, dy, L);
+                dvs_group_barrier(G, L);
+                dvs_coop_dw_bf(aW[p], ab[p], slots + (p & 1) * 2 * DVS_PKB, slots + 4 * DVS_PKB, DVS_PROJB_SLOT, L);
+                dvs_matb_T<4>(acc_dx, dvs_split_T(dy), WT + p * 2 * DVS_IMG64, WT + p * 2 * DVS_IMG64 + DVS_IMG64, 0, L);
+            }
+        };
+        run(0, split ? 1 : NPROJ, dx);
         dvs_group_barrier(G, L);        // every wave of the group is done with this DAG's slots
         if (a.ln.stats) {
             // two fp32 tiles for the column sums: each fits the [hi | lo] pair of a parked tile
@@ -463,6 +469,23 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
                 for (int t = 0; t < 4; ++t) dx[t] += old[t];
             }
             dvs_store_tile(a.gout, dag, dx, L);
+        }
+        if (split) {
+            // second input (the decoder memory: no LayerNorm), projections 1 and 2; its gradient accumulates over the layers
+            f4 x2[4], dx2[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            dvs_load_grad(x2, a.xin2, dg, Nl, L);
+            dvs_park_bf(myB, x2, L);
+            run(1, 3, dx2);
+            dvs_group_barrier(G, L);
+            if (live) {
+                if (a.accumulate_out2) {
+                    f4 old[4];
+                    dvs_load_tile(old, a.gout2, dag, L);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dx2[t] += old[t];
+                }
+                dvs_store_tile(a.gout2, dag, dx2, L);
+            }
         }
         DVS_ROUND_TOUCH_DONE(rt);
     }

@@ -121,7 +121,7 @@ void dvs_launch_ffn_bwd(const FfnBwdArgs& a, int grid, int nw, dvs_stream_t st);
 void dvs_launch_proj_bwd(const ProjBwdArgs& a, int nproj, int grid, int nw, dvs_stream_t st);
 void dvs_launch_attn_bwd(const AttnBwdArgs& a, int grid, int nw, dvs_stream_t st);
 void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st);
-void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st);
+void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, int nw, dvs_stream_t st);
 void dvs_launch_latent_bwd(const LatentBwdArgs& a, dvs_stream_t st);
 void dvs_launch_fc_dw(const FcDwArgs& a, dvs_stream_t st);
 void dvs_launch_reduce_slabs(const ReduceArgs& a, dvs_stream_t st);

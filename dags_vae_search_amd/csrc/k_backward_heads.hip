@@ -308,7 +308,7 @@ void dvs_launch_loss_bwd(const LossArgs& a, int grid, dvs_stream_t st) {
 // Handles up to two gradient sources per DAG (encoder-side and decoder-side embeddings: same weights, different
 // dropout sites).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gout2, int site2, DvsStagePlan plan) {
+__global__ __launch_bounds__(512) void k_embed_bwd(EmbedArgs a, const float* gout2, int site2, DvsStagePlan plan) {
     DVS_DYN_LDS(smem);
     const int N = a.dims.N, C = a.dims.C;
     float* W1 = (float*)smem;                        // [32][LD], rows >= 2N zero
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
     float* labw = W2 + 64 * EMB_LDW2;                // [32][16]
     float* labb = labw + 32 * 16;                    // [32]
     float* scr0 = labb + 32;                         // nwaves tiles
-    dvs_stage_now<5>(&plan, smem);           // the embedding block (dvs_wimg.h: DvsEmbImg) in one batch: 20 wave chunks on 4 waves
+    // the embedding block (dvs_wimg.h: DvsEmbImg) in one batch: 20 wave chunks on 8 waves (4 in the narrow mapping)
+    if (blockDim.x >= 512) dvs_stage_now<3>(&plan, smem);
+    else dvs_stage_now<5>(&plan, smem);
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -386,35 +388,39 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedArgs a, const float* gou
         }
     }
     __syncthreads();
+    // 8 waves (round 3; two per SIMD — the DAG loop is a chain of LDS transposes and small MFMA products, latency-bound with one):
+    // the per-wave partials meet in LDS in two passes (all four matrices at once would need 8 x 4608 floats = 147 KB)
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
-    float* r1a = (float*)smem;                 // 4 * 1024
-    float* r1b = r1a + 4 * 1024;               // 4 * 1024
-    float* rlab = r1b + 4 * 1024;              // 4 * 512
-    float* rW2 = rlab + 4 * 512;               // 4 * 2048
-    float* rv = rW2 + 4 * 2048;                // 4 * 32
+    float* r1a = (float*)smem;                 // 8 * 1024
+    float* r1b = r1a + 8 * 1024;               // 8 * 1024
+    float* rlab = r1b + 8 * 1024;              // 8 * 512
+    float* rv = rlab + 8 * 512;                // 8 * 32
     dvs_stage_dw<1, 4>(r1a, dW1a, L);
     dvs_stage_dw<1, 4>(r1b, dW1b, L);
     dvs_stage_dw<2, 1>(rlab, dlab, L);
-    dvs_stage_dw<4, 2>(rW2, dW2, L);
-    dvs_stage_vec<2>(rv, dlabb, rv + 4 * 32 + L.wave * DVS_SCR, L);
+    dvs_stage_vec<2>(rv, dlabb, rv + 8 * 32 + L.wave * DVS_SCR, L);
     __syncthreads();
     dvs_flush_dw<1, 4>(r1a, slab + a.oW1, L, N, 64);
     dvs_flush_dw<1, 4>(r1b, slab + a.oW1 + (size_t)N * 64, L, N, 64);
     dvs_flush_dw<2, 1>(rlab, slab + a.olab_w, L, 32, C, C);
-    dvs_flush_dw<4, 2>(rW2, slab + a.oW2, L);
     dvs_flush_vec<2>(rv, slab + a.olab_b, L);
+    __syncthreads();
+    float* rW2 = (float*)smem;                 // 8 * 2048
+    dvs_stage_dw<4, 2>(rW2, dW2, L);
+    __syncthreads();
+    dvs_flush_dw<4, 2>(rW2, slab + a.oW2, L);
 }
 
-void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, dvs_stream_t st) {
-    size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 4 * DVS_SCR) * 4;
-    const size_t red = (4 * (1024 + 1024 + 512 + 2048) + 4 * 32 + 4 * DVS_SCR) * 4;
+void dvs_launch_embed_bwd(const EmbedArgs& a, const float* gout2, int site2, int grid, int nw, dvs_stream_t st) {
+    size_t lds = (2 * DVS_MAXTOK * DVS_LD + 64 * EMB_LDW2 + 32 * 16 + 32 + 8 * DVS_SCR) * 4;
+    const size_t red = (8 * (1024 + 1024 + 512) + 8 * 32 + 8 * DVS_SCR) * 4;          // first epilogue pass (the second: 8 * 2048 floats)
     if (lds < red) lds = red;
     DvsStagePlan plan;
     dvs_plan_clear(plan);
     dvs_plan_seg(plan, DVS_FAKE_LDS, DVS_FAKE_LDS, a.embimg, 2 * DvsEmbImg::FLOATS);
     dvs_plan_seal(plan);
     DVS_SET_LDS(k_embed_bwd, lds);
-    DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(256), lds, st, a, gout2, site2, plan);
+    DVS_LAUNCH(k_embed_bwd, dim3(grid), dim3(nw == 4 ? 256 : 512), lds, st, a, gout2, site2, plan);     // narrow mapping: 4 waves
 }
 
 // ---------------------------------------------------------------------------------------------------------

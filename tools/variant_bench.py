@@ -23,6 +23,6 @@ for name in names:
     out = subprocess.run([sys.executable, "-c", CHILD % (name, extra)], capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        print(name, round(d["ms_per_step"], 4), {k: v for k, v in list(d["kernels"].items())[:5]}, flush=True)
+        print(name, round(d["ms_per_step"], 4), {k: v for k, v in list(d["kernels"].items())[:9]}, flush=True)
     except Exception:
         print(name, "failed", out.stderr[-800:], flush=True)

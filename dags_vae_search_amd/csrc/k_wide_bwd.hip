@@ -17,11 +17,12 @@
 // Round 2's core walked ancestor / descendant bit-rows with one lane per (token, head) on the VALU (35 k of the kernel's 48 k
 // cycles per DAG at n = 37, matrix pipe 5 % busy, 68 % of the wave cycles waiting: the walk is a chain of dependent LDS reads).
 // ---------------------------------------------------------------------------------------------------------
+constexpr int ATTNWB_TLD = 20;                   // floats per row of a transposing scratch tile (16 + 4: 16-byte rows, 2-way banks at most)
+constexpr int ATTNWB_TSCR = 2 * 16 * ATTNWB_TLD; // per wave: dS and P' tiles of the current pair (attnwb_core)
 struct AttnWBLds {
     dvs_bf16 *WoTh, *WoTl, *Winh, *Winl;     // bf16x3 pairs, in the order of the per-step block (dvs_wimg.h: WoutT, WinB)
-    float *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *O, *DQ, *lse, *delta;
-    uint64_t* al;                // [3][48] ancestor bit-rows (whom token i attends), their even / odd set bits
-    uint64_t* de;                // [3][48] descendant bit-rows (who attends token j), likewise
+    float *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *tscr;      // Q / K / V / dO end the core as dq / dk / dv / O (attnwb_core)
+    uint64_t* al;                // [48] ancestor bit-rows (whom token i attends)
 };
 __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     AttnWBLds l;
@@ -37,32 +38,51 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     l.K = l.Q + DVS_WSCR;
     l.V = l.K + DVS_WSCR;
     l.DO = l.V + DVS_WSCR;
-    l.O = l.DO + DVS_WSCR;
-    l.DQ = l.O + DVS_WSCR;
-    l.lse = l.DQ + DVS_WSCR;                     // [8][48]
-    l.delta = l.lse + 8 * DVS_WTOK;              // [8][48]
-    l.al = (uint64_t*)(l.delta + 8 * DVS_WTOK);  // [48] (offset is a multiple of 8 bytes)
-    l.de = l.al + 3 * DVS_WTOK;
+    l.tscr = l.DO + DVS_WSCR;                    // [8 waves][2][16][ATTNWB_TLD]
+    l.al = (uint64_t*)(l.tscr + 8 * ATTNWB_TSCR);   // (offset is a multiple of 8 bytes)
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 6 * (size_t)DVS_WSCR + 16 * DVS_WTOK + 12 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR + 8 * ATTNWB_TSCR + 2 * DVS_WTOK;
 
+
+#ifdef DVS_STAMPS
+// per-stage s_memtime totals of k_attn_bwd_w (tools/wide_stamps.py): [workgroup][wave][stage], summed over DAGs and launches
+__device__ unsigned long long dvs_stamps_wb[256 * 8 * 8];
+#define WBSTAMP(k)                                                                                          \
+    do {                                                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) dvs_stamps_wb[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] += now_ - wst_; \
+        wst_ = now_;                                                                                        \
+    } while (0)
+extern "C" int dvs_debug_read_stamps_wb(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_wb)) bytes = sizeof(dvs_stamps_wb);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_wb), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_wb)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_wb)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#else
+#define WBSTAMP(k) ((void)0)
+#endif
 
 // ---- MFMA core of the wide attention backward ----------------------------------------------------------------------------
 // Wave h owns head h: it touches ONLY the head's 8 feature columns c0 = 8h .. of the parked [48][DVS_LD] buffers, so the eight
-// waves need no synchronisation among themselves (dk / dv overwrite K / V in place).  Every MFMA operand of the head is loaded
-// from LDS, as two kinds of fragments per 16-token tile t:
+// waves need no synchronisation among themselves, and every result overwrites its own operand in place: dq the rows of Q, O the
+// rows of dO (per query tile, once the tile's fragments are in registers), dk / dv the K and V buffers (after the last query
+// tile).  Every MFMA operand of the head is loaded from LDS, as two kinds of fragments per 16-token tile t:
 //   row[s]   = X[16t + r][c0 + 4s + g]          s = 0, 1     contraction over the head's 8 features (two K = 4 steps)
 //   col[reg] = X[16t + 4g + reg][c0 + (r & 7)]  reg = 0..3   contraction over the tile's 16 tokens (four K = 4 steps); A-operand
 //                                                            rows r >= 8 duplicate r - 8 and their result rows are ignored
-// (fragments are fetched where they are used).  For the in-place dk / dv: the K and V col fragments are read in the T pass only,
-// which ends before the S pass writes anything; the S pass reads the row fragments of key tile jt before it writes that tile.
-// Score tiles in both orientations come from the SAME registers with the operands swapped (dvs_device.h):
-//   T: S^T = K Q^T  -> reg <-> key j = 16jt + 4g + reg, lane r <-> query i      (row statistics in-lane + 2 swaps, dq, O)
-//   S: S   = Q K^T  -> reg <-> query i = 16it + 4g + reg, lane r <-> key j      (dk, dv)
-// and a D-layout register `reg` IS the B operand of contraction step `reg` (k = g <-> token 4g + reg).  Tile pairs whose
-// 16 x 16 block of the mask is empty — all pairs above the diagonal for DAGs in topological vertex order, more for sparse ones —
-// are skipped: `pairs` bit 3 it + jt.  Per pair: 12 MFMAs in each orientation.
+// ONE pass over the query tiles, in the T orientation  S^T = K Q^T  (reg <-> key j = 16jt + 4g + reg, lane r <-> query i): row
+// statistics in-lane + 2 swaps, and a D-layout register `reg` IS the B operand of contraction step `reg` (k = g <-> token
+// 4g + reg) for dq and O.  dk and dv contract over the QUERIES, i.e. need dS and P' with lane r <-> key j: the two 16 x 16 tiles
+// of a pair go through a per-wave LDS scratch (one 16-byte write per lane and tile, four 4-byte transposed reads) — round 3's
+// first version recomputed scores, exponentials and the dropout draws of every pair in a second pass with the operands
+// swapped (8.7 k of the core's 26 k cycles per DAG, `profiles/r03_wide_stamps_bwd.txt`).  Tile pairs whose 16 x 16 block of the
+// mask is empty — all pairs above the diagonal for DAGs in topological vertex order, more for sparse ones — are skipped:
+// `pairs` bit 3 it + jt.  Per pair 20 MFMAs.
 // fragments are fetched where they are used (cheap: 4-byte LDS reads; the kernel is register-bound, not LDS-bound)
 __device__ __forceinline__ void attnwb_row(float (&f)[2], const float* X, int t, int c0, const Lane& L) {
     const float* p = X + (16 * t + L.r) * DVS_LD + c0 + L.g;
@@ -86,17 +106,16 @@ __device__ __forceinline__ f4 attnwb_mask_T(uint32_t key, int h, int i, int j0, 
     m[3] = ((h1 >> 16) >= D.thr16) ? D.scale : 0.f;
     return m;
 }
-// S orientation: key j = lane's, queries i0 .. i0 + 3: one draw per element (the pair partner j ^ 1 lives in another lane)
-__device__ __forceinline__ f4 attnwb_mask_S(uint32_t key, int h, int i0, int j, int NTOK, const DvsDrop& D) {
-    if (!D.on) return f4_splat(1.f);
-    f4 m;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) m[reg] = dvs_dropout_elem(1.0f, key, (uint32_t)((h * NTOK + i0 + reg) * NTOK + j), D);
-    return m;
+// a T-orientation tile (lane (r, g) holds (row r, columns 4g ..)) through the wave's scratch: out[reg] = element (row 4g + reg, column r)
+__device__ __forceinline__ void attnwb_put(float* scr, const f4& v, const Lane& L) { *(f4*)(scr + L.r * ATTNWB_TLD + 4 * L.g) = v; }
+__device__ __forceinline__ f4 attnwb_get(const float* scr, const Lane& L) {
+    const float* p = scr + (4 * L.g) * ATTNWB_TLD + L.r;
+    return f4{p[0], p[ATTNWB_TLD], p[2 * ATTNWB_TLD], p[3 * ATTNWB_TLD]};
 }
 __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, int NT, uint32_t kprob, const DvsDrop& D, float scale,
-                                            const Lane& L) {
+                                            const Lane& L, unsigned long long& wst_) {
     const int c0 = 8 * h, NTOK = 16 * NT;
+    float* const tscr = l.tscr + L.wave * ATTNWB_TSCR;
     // non-empty tile pairs, from the DAG's 48 ancestor rows: lane i < 48 holds row i
     uint32_t pairs = 0;
     {
@@ -109,13 +128,16 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
                 if ((b >> (16 * it)) & 0xFFFFull) pairs |= 1u << (3 * it + jt);
         }
     }
-    // ---- T orientation: per query tile ------------------------------------------------------------------------------------
+    f4 dk[DVS_WNT], dv[DVS_WNT];
+#pragma unroll
+    for (int jt = 0; jt < DVS_WNT; ++jt) dk[jt] = dv[jt] = f4_zero();
     for (int it = 0; it < NT; ++it) {
         const int i = 16 * it + L.r;
         const uint64_t row = l.al[i];
         float fq[2], fg[2];
         attnwb_row(fq, l.Q, it, c0, L);
         attnwb_row(fg, l.DO, it, c0, L);
+        const f4 qc = attnwb_col(l.Q, it, c0, L), gc = attnwb_col(l.DO, it, c0, L);     // for dk, dv: this tile's rows are overwritten below
         f4 sT[DVS_WNT], dpT[DVS_WNT];
         float m = -3.0e38f;
 #pragma unroll
@@ -166,62 +188,42 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
 #pragma unroll
         for (int jt = 0; jt < DVS_WNT; ++jt) {
             if (!((pairs >> (3 * it + jt)) & 1u)) continue;
+            f4 ds;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ds[reg] = sT[jt][reg] * (dpT[jt][reg] - delta);
+            attnwb_put(tscr, ds, L);
+            attnwb_put(tscr + 16 * ATTNWB_TLD, pmk[jt], L);
             const f4 kc = attnwb_col(l.K, jt, c0, L), vc = attnwb_col(l.V, jt, c0, L);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float ds = sT[jt][reg] * (dpT[jt][reg] - delta);
-                dq = dvs_mfma(kc[reg], ds, dq);
+                dq = dvs_mfma(kc[reg], ds[reg], dq);
                 o = dvs_mfma(vc[reg], pmk[jt][reg], o);
             }
-        }
-        // D[row f = 4g + reg][col i = r]: the head's 8 features live in the lane groups g = 0, 1
-        if (L.g < 2) {
-            *(f4*)(l.DQ + i * DVS_LD + c0 + 4 * L.g) = dq * scale;
-            *(f4*)(l.O + i * DVS_LD + c0 + 4 * L.g) = o;
-        }
-        if (L.g == 0) {
-            l.lse[h * DVS_WTOK + i] = den > 0.f ? m + __logf(den) : 0.f;
-            l.delta[h * DVS_WTOK + i] = delta;
-        }
-    }
-    dvs_wave_sync();             // lse / delta: written by lanes g = 0, read by every lane of this wave below
-    // ---- S orientation: per key tile.  K / V fragments of tile jt first, its dk / dv rows (this head's columns) last: a later
-    //      key tile reads other rows, the T pass above is over ---------------------------------------------------------------
-    for (int jt = 0; jt < NT; ++jt) {
-        const int j = 16 * jt + L.r;
-        float fk[2], fv[2];
-        attnwb_row(fk, l.K, jt, c0, L);
-        attnwb_row(fv, l.V, jt, c0, L);
-        f4 dk = f4_zero(), dv = f4_zero();
-#pragma unroll
-        for (int it = 0; it < DVS_WNT; ++it) {
-            if (!((pairs >> (3 * it + jt)) & 1u)) continue;
-            float fq[2], fg[2];
-            attnwb_row(fq, l.Q, it, c0, L);
-            attnwb_row(fg, l.DO, it, c0, L);
-            f4 s2 = f4_zero(), dp = f4_zero();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                s2 = dvs_mfma(fq[s], fk[s], s2);
-                dp = dvs_mfma(fg[s], fv[s], dp);
-            }
-            const int i0 = 16 * it + 4 * L.g;
-            const f4 lse4 = *(const f4*)(l.lse + h * DVS_WTOK + i0), del4 = *(const f4*)(l.delta + h * DVS_WTOK + i0);
-            const f4 mk = attnwb_mask_S(kprob, h, i0, j, NTOK, D);
-            const f4 qc = attnwb_col(l.Q, it, c0, L), gc = attnwb_col(l.DO, it, c0, L);
+            dvs_wave_sync();
+            const f4 dsS = attnwb_get(tscr, L), pS = attnwb_get(tscr + 16 * ATTNWB_TLD, L);       // (query 4g + reg, key r)
+            dvs_wave_sync();
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const bool ok = (l.al[i0 + reg] >> j) & 1ull;
-                const float p = ok ? __expf(s2[reg] - lse4[reg]) : 0.f;
-                const float ds = p * (dp[reg] * mk[reg] - del4[reg]);
-                dk = dvs_mfma(qc[reg], ds, dk);
-                dv = dvs_mfma(gc[reg], p * mk[reg], dv);
+                dk[jt] = dvs_mfma(qc[reg], dsS[reg], dk[jt]);
+                dv[jt] = dvs_mfma(gc[reg], pS[reg], dv[jt]);
             }
         }
-        dvs_wave_sync();         // every lane's reads of this tile's K / V rows are done (in-order LDS queue of the wave)
+        // D[row f = 4g + reg][col i = r]: the head's 8 features live in the lane groups g = 0, 1.  In place: this query tile's
+        // fragments of Q and dO are in registers (in-order LDS queue of the wave: the reads above are ahead of these writes)
+        dvs_wave_sync();
         if (L.g < 2) {
-            *(f4*)(l.K + j * DVS_LD + c0 + 4 * L.g) = dk;
-            *(f4*)(l.V + j * DVS_LD + c0 + 4 * L.g) = dv;
+            *(f4*)(l.Q + i * DVS_LD + c0 + 4 * L.g) = dq * scale;
+            *(f4*)(l.DO + i * DVS_LD + c0 + 4 * L.g) = o;
+        }
+    }
+    WBSTAMP(3);
+    dvs_wave_sync();
+#pragma unroll
+    for (int jt = 0; jt < DVS_WNT; ++jt) {
+        if (jt < NT && L.g < 2) {
+            const int j = 16 * jt + L.r;
+            *(f4*)(l.K + j * DVS_LD + c0 + 4 * L.g) = dk[jt];
+            *(f4*)(l.V + j * DVS_LD + c0 + 4 * L.g) = dv[jt];
         }
     }
 }
@@ -229,6 +231,10 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
 // 8 waves: waves 0..NT-1 own the tiles (stores, parked d y / O); waves 0..3 accumulate dWo; in the core wave h owns head h.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
+    unsigned long long wst_ = 0;
+#ifdef DVS_STAMPS
+    wst_ = __builtin_amdgcn_s_memtime();
+#endif
     const AttnWBLds l = attnwb_lds(smem);
     dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(8 * DVS_IMG64));     // WoutT pair, Win hi / mid
     dvs_stage_vector(l.inb, a.in_b, 192);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
         dvs_stage_vector(l.lg, a.ln.g, 64);
         dvs_stage_vector(l.lb, a.ln.b, 64);
     }
-    for (int i = threadIdx.x; i < 6 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     // d out_proj.weight / bias, cooperatively (dvs_backward.h): wave w < 4 accumulates rows 16w .. of dWo over the DAG's tiles —
     // 16 accumulator registers per wave instead of 64 (all eight waves would carry them through the core)
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, abo = f4_zero();
+    WBSTAMP(0);
     for (int dag = blockIdx.x; dag < B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
@@ -313,17 +320,21 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
                 }
             }
         }
+        WBSTAMP(1);
         __syncthreads();
+        WBSTAMP(2);
         // ---- core: wave h = head h, on the matrix pipe (attnwb_core below) ----------------------------------------------
-        attnwb_core(l, L.wave, N, NT, kprob, D, scale, L);
+        attnwb_core(l, L.wave, N, NT, kprob, D, scale, L, wst_);
+        WBSTAMP(4);
         __syncthreads();
+        WBSTAMP(5);
         if (has_tile) {
             const bool valid = L.r < Nl;
             f4 dy[4];                 // stage 1 computed dO on other waves: this tile's masked d pre again, for dWo / dbo
             dvs_load_grad(dy, a.gpre, tile, Nl, L);
             dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
             f4 g[4];
-            dvs_lds_T(g, l.DQ, tok0, L);
+            dvs_lds_T(g, l.Q, tok0, L);                  // d q (in place, attnwb_core)
 #pragma unroll
             for (int t = 0; t < 4; ++t) g[t] = valid ? g[t] : f4_zero();
             dvs_store_tile(a.gq, tile, g, L);
@@ -338,16 +349,18 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             // dWo += dy^T O, dbo += column sums of dy: both tiles parked as bf16 [hi | lo] pairs for the cooperative product
             // below — d y over this tile's rows of Q (free now), O converted in place (a pair is exactly the 16 fp32 rows it replaces)
             f4 o[4];
-            dvs_lds_T(o, l.O, tok0, L);
+            dvs_lds_T(o, l.DO, tok0, L);                 // O (in place)
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = valid ? o[t] : f4_zero();
             dvs_wave_sync();
             dvs_park_bf((dvs_bf16*)(l.Q + tok0 * DVS_LD), dy, L);
-            dvs_park_bf((dvs_bf16*)(l.O + tok0 * DVS_LD), o, L);
+            dvs_park_bf((dvs_bf16*)(l.DO + tok0 * DVS_LD), o, L);
         }
+        WBSTAMP(6);
         __syncthreads();
-        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)l.O, NT, L);
+        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)l.DO, NT, L);
         __syncthreads();
+        WBSTAMP(7);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;

@@ -15,10 +15,15 @@ f = prepare_features(synthetic_dags(37, 37, 2048, seed=42, density_limit=0.2), 4
 f = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in f.items()}
 for _ in range(2): train_batch(f, model, opt)
 torch.cuda.synchronize()
-fn = lib.dvs_debug_read_stamps_w; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+fn = lib.dvs_debug_read_stamps_wb if which == "bwd" else lib.dvs_debug_read_stamps_w; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 buf = np.zeros(256*8*8, np.uint64); fn(buf.ctypes.data, buf.nbytes, 1)
 train_batch(f, model, opt); torch.cuda.synchronize()
 fn(buf.ctypes.data, buf.nbytes, 0)
 t = buf.reshape(256, 8, 8).astype(np.float64) / (9 * 8)     # 9 launches x 8 DAGs per workgroup
-print("cycles per DAG (mean over WGs): k: 0 prologue(per launch/72) 1 stage1 2 barrier 3 stage2 4 barrier 5 stage3 6 barrier")
-for w in range(8): print("wave", w, np.round(t[:, w, :7].mean(0)).astype(int).tolist(), "sum", int(t[:, w, 1:7].mean(0).sum()))
+if which == "bwd":
+    print("k_attn_bwd_w, cycles per DAG (mean over WGs): 0 prologue(per launch/72) 1 stage1 2 barrier 3 core T pass 4 core S pass 5 barrier 6 stores / parks 7 barrier + dWo + barrier")
+    for w in range(8): print("wave", w, np.round(t[:, w, :8].mean(0)).astype(int).tolist(), "sum", int(t[:, w, 1:8].mean(0).sum()))
+else:
+    print("k_attn_fwd_w, cycles per DAG (mean over WGs): k: 0 prologue(per launch/72) 1 stage1 2 barrier 3 stage2 4 barrier 5 stage3 6 barrier")
+    for w in range(8): print("wave", w, np.round(t[:, w, :7].mean(0)).astype(int).tolist(), "sum", int(t[:, w, 1:7].mean(0).sum()))

@@ -38,11 +38,12 @@ __device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
     l.K = l.Q + DVS_WSCR;
     l.V = l.K + DVS_WSCR;
     l.DO = l.V + DVS_WSCR;
-    l.tscr = l.DO + DVS_WSCR;                    // [8 waves][2][16][ATTNWB_TLD]
+    l.tscr = l.DO + 2 * DVS_WSCR;                // (two dO buffers: k_attn_bwd_w) [8 waves][2][16][ATTNWB_TLD]
     l.al = (uint64_t*)(l.tscr + 8 * ATTNWB_TSCR);   // (offset is a multiple of 8 bytes)
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 4 * (size_t)DVS_WSCR + 8 * ATTNWB_TSCR + 2 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 5 * (size_t)DVS_WSCR + 8 * ATTNWB_TSCR + 2 * DVS_WTOK;
+static_assert(ATTNWB_FLOATS * 4 <= 160 * 1024, "k_attn_bwd_w LDS");
 
 
 #ifdef DVS_STAMPS
@@ -131,7 +132,14 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
     f4 dk[DVS_WNT], dv[DVS_WNT];
 #pragma unroll
     for (int jt = 0; jt < DVS_WNT; ++jt) dk[jt] = dv[jt] = f4_zero();
-    for (int it = 0; it < NT; ++it) {
+    // the two waves of a SIMD (heads h and h + 4) walk the query tiles in opposite directions: a late tile has more key tiles,
+    // so the softmax arithmetic of one wave falls on the MFMA chains of the other instead of both colliding on the same pipe
+    for (int ii = 0; ii < NT; ++ii) {
+#ifdef DVS_WB_NOREV
+        const int it = ii;
+#else
+        const int it = h >= 4 ? NT - 1 - ii : ii;
+#endif
         const int i = 16 * it + L.r;
         const uint64_t row = l.al[i];
         float fq[2], fg[2];
@@ -228,7 +236,38 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
     }
 }
 
-// 8 waves: waves 0..NT-1 own the tiles (stores, parked d y / O); waves 0..3 accumulate dWo; in the core wave h owns head h.
+// dO^T = Wo^T dropout-mask(d pre) of DAG `dag`, parked in `DO`: the 4 NT output tiles (unit u = 4 tile + ot) are shared by the
+// `nw` waves that take part (wave index wi), every wave inside ONE token tile (a tile costs a load, the dropout draws and the
+// bf16 split before its first product).
+__device__ __forceinline__ void attnwb_do_job(const AttnWBLds& l, float* DO, const AttnBwdArgs& a, int dag, int wi, int nw,
+                                              const DvsDrop& D, const Lane& L) {
+    const int N = a.dims.N, NT = a.dims.NT;
+    const int per = nw < 2 * NT ? 4 : (nw < 4 * NT ? 2 : 1);
+    const int u0 = wi * per, u1 = (u0 + per < 4 * NT) ? u0 + per : 4 * NT;
+    if (u0 >= u1) return;
+    const int tw = u0 >> 2;
+    const uint32_t gdag = a.dims.dag_offset + dag;
+    f4 dyt[4];
+    dvs_load_grad(dyt, a.gpre, (size_t)dag * NT + tw, dvs_rows_of(N, tw), L);
+    dvs_dropout_tile(dyt, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, 16 * tw);
+    const SplitT ds = dvs_split_T(dyt);
+    for (int u = u0; u < u1; ++u) {
+        const int ot = u & 3;
+        f4 o1[1] = {f4_zero()};
+        dvs_matb_T<1>(o1, ds, l.WoTh, l.WoTl, 16 * ot, L);
+        dvs_park_col(DO, 16 * tw, ot, o1[0], L);
+    }
+}
+
+// 8 waves.  Per DAG:
+//   stage 1 : q, k, v of every tile (bf16x3 from the per-step images: q, k, v feed a softmax — smooth, as in the one-tile
+//             backward), the 12 NT output tiles shared evenly by the eight waves, parked in LDS                | barrier
+//   core    : wave h = head h (attnwb_core)                                                                   | barrier
+//   tail    : waves 0..NT-1 own the tiles: store dq, dk, dv, park d y and O as bf16 pairs | barrier | waves 0..3: dWo += dy^T O
+//             cooperatively.  Waves 4..7 have no part in that: they compute dO^T of the workgroup's NEXT DAG into the other
+//             of two dO buffers (the first DAG's is computed by all waves ahead of the loop)                    | barrier
+// Round 3's first version computed dO inside stage 1 on two waves, which then took 10.1 k cycles against 5.3-6.5 k of the six
+// projection waves, while waves 4-7 idled through the 4.7 k of the tail (`profiles/r03_wide_stamps_bwd.txt`).
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     unsigned long long wst_ = 0;
@@ -243,94 +282,102 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
         dvs_stage_vector(l.lg, a.ln.g, 64);
         dvs_stage_vector(l.lb, a.ln.b, 64);
     }
-    for (int i = threadIdx.x; i < 4 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
+    for (int i = threadIdx.x; i < 5 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
-    const int N = a.dims.N, NT = a.dims.NT, NTOK = 16 * NT, B = a.dims.B;
+    const int N = a.dims.N, NT = a.dims.NT, B = a.dims.B;
     const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
     const bool has_tile = L.wave < NT;
-    const int pw = L.wave >> 1, phalf = L.wave & 1;              // stage 1: (tile, half of the in-projection rows)
-    const bool proj = L.wave < 2 * NT;
     const float scale = 0.35355339059327373f;
     // d out_proj.weight / bias, cooperatively (dvs_backward.h): wave w < 4 accumulates rows 16w .. of dWo over the DAG's tiles —
     // 16 accumulator registers per wave instead of 64 (all eight waves would carry them through the core)
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, abo = f4_zero();
+    int cur = 0;
+    if ((int)blockIdx.x < B) attnwb_do_job(l, l.DO, a, blockIdx.x, L.wave, 8, D, L);
     WBSTAMP(0);
     for (int dag = blockIdx.x; dag < B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {      // a wave without a tile prepares the rows
+        AttnWBLds lc = l;
+        lc.DO = l.DO + cur * DVS_WSCR;
+        float* const DOnext = l.DO + (cur ^ 1) * DVS_WSCR;
+        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {
             const int i = threadIdx.x - 256;
             l.al[i] = i < N ? rec->allowed[i] : 0ull;
         }
-        // ---- stage 1: all 8 waves, bf16x3 (q, k, v feed a softmax, dO is a gradient product: smooth, as in the one-tile backward) ----
-        if (proj) {
-            const size_t ptile = (size_t)dag * NT + pw;
-            const int ptok0 = 16 * pw, pNl = dvs_rows_of(N, pw);
-            f4 x[4], kv[4], dummy[4];
-            float rstd;
-            dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, ptile, pNl, L);
-            if (a.kv) {
-                dvs_load_tile(kv, a.kv, ptile, L);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) kv[t] = x[t];
-            }
-            const SplitT kvs = dvs_split_T(kv);
-            if (phalf == 0) {
-                f4 q[4], k01[2];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) q[t] = dvs_vecT(l.inb, t, L);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) k01[t] = dvs_vecT(l.inb + 64, t, L);
-                dvs_matb_T<4>(q, dvs_split_T(x), l.Winh, l.Winl, 0, L);
-                dvs_matb_T<2>(k01, kvs, l.Winh, l.Winl, 64, L);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dvs_park_col(l.Q, ptok0, t, q[t] * scale, L);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, t, k01[t], L);
-            } else {
-                f4 k23[2], v[4];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) k23[t] = dvs_vecT(l.inb + 96, t, L);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = dvs_vecT(l.inb + 128, t, L);
-                dvs_matb_T<2>(k23, kvs, l.Winh, l.Winl, 96, L);
-                dvs_matb_T<4>(v, kvs, l.Winh, l.Winl, 128, L);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, 2 + t, k23[t], L);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dvs_park_col(l.V, ptok0, t, v[t], L);
-            }
-        } else {
-            // dO^T of every tile, output tiles ot = dw, dw + ndw, .. of each (ndw = 8 - 2 NT waves share them)
-            const int dw = L.wave - 2 * NT, ndw = 8 - 2 * NT;
-            for (int tw = 0; tw < NT; ++tw) {
-                f4 dyt[4];
-                dvs_load_grad(dyt, a.gpre, (size_t)dag * NT + tw, dvs_rows_of(N, tw), L);
-                dvs_dropout_tile(dyt, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, 16 * tw);
-                const SplitT ds = dvs_split_T(dyt);
-                for (int ot = dw; ot < 4; ot += ndw) {
-                    f4 o1[1] = {f4_zero()};
-                    dvs_matb_T<1>(o1, ds, l.WoTh, l.WoTl, 16 * ot, L);
-                    dvs_park_col(l.DO, 16 * tw, ot, o1[0], L);
+        // ---- stage 1: output tile u = 12 tile + o12 (o12: 0-3 q of x, 4-7 k and 8-11 v of the key / value input) ----------
+        {
+            const int nunits = 12 * NT;
+            int u = nunits * L.wave / 8;
+            const int u1 = nunits * (L.wave + 1) / 8;
+            int ct = -1;
+            SplitT xs, kvs;
+            for (; u < u1; ++u) {
+                const int t = u / 12, o12 = u - 12 * t;
+                if (t != ct) {               // (a wave's range crosses at most one tile boundary)
+                    ct = t;
+                    const size_t ptile = (size_t)dag * NT + t;
+                    f4 x[4], dummy[4];
+                    float rstd;
+                    dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, ptile, dvs_rows_of(N, t), L);
+                    xs = dvs_split_T(x);
+                    if (a.kv) {
+                        f4 kv[4];
+                        dvs_load_tile(kv, a.kv, ptile, L);
+                        kvs = dvs_split_T(kv);
+                    } else {
+                        kvs = xs;
+                    }
                 }
+                f4 o1[1] = {dvs_vecT(l.inb + 16 * o12, 0, L)};
+                if (o12 < 4) dvs_matb_T<1>(o1, xs, l.Winh, l.Winl, 16 * o12, L);
+                else dvs_matb_T<1>(o1, kvs, l.Winh, l.Winl, 16 * o12, L);
+                float* const buf = o12 < 4 ? l.Q : (o12 < 8 ? l.K : l.V);
+                dvs_park_col(buf, 16 * t, o12 & 3, o12 < 4 ? o1[0] * scale : o1[0], L);
             }
         }
         WBSTAMP(1);
         __syncthreads();
         WBSTAMP(2);
-        // ---- core: wave h = head h, on the matrix pipe (attnwb_core below) ----------------------------------------------
-        attnwb_core(l, L.wave, N, NT, kprob, D, scale, L, wst_);
+        // every wave touches the tiles it loads next — the workgroup's next DAG's stage-1 inputs, the d pre tile of the tail —
+        // ahead of the core, one 4-byte load per lane and tile (a lane per 64 bytes: every line of the tile), kept in a register
+        // until the core is over: the tiles arrive in the cache while the core runs on LDS only (as dvs_touch_first does between
+        // the phases of the chained kernels; stage 1 and the tail were 30-50 % cold-load latency)
+        float tch[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const int nd = dag + (int)gridDim.x;
+            const size_t loff = (size_t)L.lane * 16;
+            if (nd < B) {
+                const int nunits = 12 * NT;
+                const size_t ta = (size_t)nd * NT + (nunits * L.wave / 8) / 12, tb = (size_t)nd * NT + (nunits * (L.wave + 1) / 8 - 1) / 12;
+                tch[0] = a.xin[ta * 1024 + loff];
+                tch[1] = a.xin[tb * 1024 + loff];
+                if (a.kv) {
+                    tch[2] = a.kv[ta * 1024 + loff];
+                    tch[3] = a.kv[tb * 1024 + loff];
+                }
+            }
+            if (has_tile) {
+                tch[4] = a.gpre[tile * 1024 + loff];
+            } else if (L.wave >= 4 && nd < B) {
+                const int per = 4 < 2 * NT ? 4 : 2, u0 = (L.wave - 4) * per;       // attnwb_do_job with 4 waves
+                if (u0 < 4 * NT) tch[4] = a.gpre[((size_t)nd * NT + (u0 >> 2)) * 1024 + loff];
+            }
+        }
+        // ---- core: wave h = head h, on the matrix pipe (attnwb_core above) ----------------------------------------------
+        attnwb_core(lc, L.wave, N, NT, kprob, D, scale, L, wst_);
+#ifndef DVS_EMU
+        asm volatile("" ::"v"(tch[0]), "v"(tch[1]), "v"(tch[2]), "v"(tch[3]), "v"(tch[4]));
+#endif
         WBSTAMP(4);
         __syncthreads();
         WBSTAMP(5);
         if (has_tile) {
             const bool valid = L.r < Nl;
-            f4 dy[4];                 // stage 1 computed dO on other waves: this tile's masked d pre again, for dWo / dbo
+            f4 dy[4];                 // this tile's masked d pre again, for dWo / dbo
             dvs_load_grad(dy, a.gpre, tile, Nl, L);
             dvs_dropout_tile(dy, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, tok0);
             f4 g[4];
@@ -349,18 +396,21 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             // dWo += dy^T O, dbo += column sums of dy: both tiles parked as bf16 [hi | lo] pairs for the cooperative product
             // below — d y over this tile's rows of Q (free now), O converted in place (a pair is exactly the 16 fp32 rows it replaces)
             f4 o[4];
-            dvs_lds_T(o, l.DO, tok0, L);                 // O (in place)
+            dvs_lds_T(o, lc.DO, tok0, L);                // O (in place)
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = valid ? o[t] : f4_zero();
             dvs_wave_sync();
             dvs_park_bf((dvs_bf16*)(l.Q + tok0 * DVS_LD), dy, L);
-            dvs_park_bf((dvs_bf16*)(l.DO + tok0 * DVS_LD), o, L);
+            dvs_park_bf((dvs_bf16*)(lc.DO + tok0 * DVS_LD), o, L);
+        } else if (L.wave >= 4 && dag + (int)gridDim.x < B) {
+            attnwb_do_job(l, DOnext, a, dag + gridDim.x, L.wave - 4, 4, D, L);
         }
         WBSTAMP(6);
         __syncthreads();
-        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)l.DO, NT, L);
+        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)lc.DO, NT, L);
         __syncthreads();
         WBSTAMP(7);
+        cur ^= 1;
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;

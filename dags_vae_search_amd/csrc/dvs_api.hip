@@ -223,7 +223,7 @@ DvsLayout dvs_make_layout(int N, int C, dvs_param_entry* table, int cap, int* co
     return l;
 }
 
-DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab) {
+DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab, bool wide) {
     DvsWorkspace w;
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -256,6 +256,7 @@ DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab) {
     w.fcpart = take((size_t)DVS_FC_PARTS * (size_t)P);
     w.wimg = take((DVS_WIMG_BF16 + 1) / 2);
     w.limg = take(DvsLatImg::floats(NT));
+    for (int blk = 0; blk < 9; ++blk) w.qkv[blk] = take(wide ? (size_t)B * NT * 12 * 256 : 0);
     w.total_floats = off;
     return w;
 }
@@ -272,6 +273,7 @@ static int check_shape(const dvs_shape* s) {
     return 0;
 }
 
+static bool is_wide(const dvs_shape* s);
 static int64_t param_floats(const dvs_shape* s) { return dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total; }
 int dvs_num_slabs();
 
@@ -295,7 +297,7 @@ static int check_buffers(const dvs_shape* s, const char* fn, bool has_records, s
         }
     }
     if (has_ws) {
-        const size_t need = dvs_make_workspace(s->batch, (s->n_tokens + 15) / 16, param_floats(s), dvs_num_slabs()).total_floats * sizeof(float);
+        const size_t need = dvs_make_workspace(s->batch, (s->n_tokens + 15) / 16, param_floats(s), dvs_num_slabs(), is_wide(s)).total_floats * sizeof(float);
         if (workspace_bytes < need) {
             snprintf(msg, sizeof(msg), "%s: workspace_bytes %zu < dvs_workspace_bytes = %zu", fn, workspace_bytes, need);
             return fail(14, msg);
@@ -376,7 +378,7 @@ extern "C" int dvs_param_table(const dvs_shape* s, dvs_param_entry* out, int cap
 extern "C" size_t dvs_workspace_bytes(const dvs_shape* s) {
     if (check_shape(s)) return 0;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
-    return dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs()).total_floats * sizeof(float);
+    return dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs(), is_wide(s)).total_floats * sizeof(float);
 }
 
 extern "C" size_t dvs_record_bytes(const dvs_shape* s) {
@@ -543,6 +545,7 @@ struct FwdGrids {
     int tiles8;     // 8-wave tile-parallel kernels (one-tile k_attn_fwd / k_embed_fwd / k_loss_fwd)
     int tiles4;     // 4-wave tile-parallel kernels (k_embed_fwd_w)
     int dags;       // workgroup-per-DAG kernels of the wide path
+    int dags2;      // ... those that fit two workgroups per CU
 };
 static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
     FwdGrids g;
@@ -554,6 +557,7 @@ static FwdGrids fwd_grids(const DvsDims& d, bool wide) {
     g.tiles8 = grid_for(d.B * d.NT, 8);
     g.tiles4 = grid_for(d.B * d.NT, 4);
     g.dags = grid_for(d.B, 1);
+    g.dags2 = d.B < 2 * g.dags ? d.B : 2 * g.dags;      // kernels that fit two workgroups per CU (k_loss_fwd_w)
     return g;
 }
 static void launch_embed_fwd(const EmbedArgs& e, const FwdGrids& g, dvs_stream_t st) {
@@ -613,7 +617,7 @@ struct FwdChain {
 // lat: the latent block's arguments; it runs as the last phase of the encoder chain when there is one, as k_latent_fwd otherwise
 static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorkspace& W, const DvsRecord* rec,
                             const float* P, float* ws, const FwdGrids& grid, dvs_stream_t st, const LatentArgs& lat,
-                            bool dec_embed = false) {
+                            bool dec_embed = false, bool save_qkv = false) {
     EmbedArgs e;
     memset(&e, 0, sizeof(e));
     e.dims = d;
@@ -646,6 +650,7 @@ static void encoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.out_w = P + L.enc[i].sa.out_w;
         a.out_b = P + L.enc[i].sa.out_b;
         a.wimg = wimg_attn(ws, W, blk_enc_attn(i));
+        a.qkv = (save_qkv && grid.wide) ? ws + W.qkv[blk_enc_attn(i)] : nullptr;
         const int sa = slot_enc(i, 0);
         a.out_pre = ws + W.act[sa];
         a.out_stats = ws + W.stats[sa];
@@ -745,6 +750,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         a.out_w = params + pl.sa.out_w;
         a.out_b = params + pl.sa.out_b;
         a.wimg = wimg_attn(ws, W, blk_dec_self(i));
+        a.qkv = grid.wide ? ws + W.qkv[blk_dec_self(i)] : nullptr;
         const int s0 = slot_dec(i, 0);
         a.out_pre = ws + W.act[s0];
         a.out_stats = ws + W.stats[s0];
@@ -764,6 +770,7 @@ static void decoder_forward(const DvsDims& d, const DvsLayout& L, const DvsWorks
         c.out_w = params + pl.ca.out_w;
         c.out_b = params + pl.ca.out_b;
         c.wimg = wimg_attn(ws, W, blk_dec_cross(i));
+        c.qkv = grid.wide ? ws + W.qkv[blk_dec_cross(i)] : nullptr;
         const int s1 = slot_dec(i, 1);
         c.out_pre = ws + W.act[s1];
         c.out_stats = ws + W.stats[s1];
@@ -810,7 +817,7 @@ extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, 
     call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs(), is_wide(s));
     float* ws = (float*)workspace;
     const DvsRecord* rec = (const DvsRecord*)records;
     dvs_stream_t st = (dvs_stream_t)stream;
@@ -818,7 +825,7 @@ extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, 
 
     prepare_images(L, d.N, d.C, grid.wide, params, ws, W, st);
     const bool fused_dec_embed = d.drop.on && !grid.wide;
-    encoder_forward(d, L, W, rec, params, ws, grid, st, latent_args(d, L, W, params, ws, eps, true), fused_dec_embed);
+    encoder_forward(d, L, W, rec, params, ws, grid, st, latent_args(d, L, W, params, ws, eps, true), fused_dec_embed, true);
 
     // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it
     // only to redraw the dropout masks)
@@ -839,7 +846,7 @@ extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, 
         dec_in = 7;
     }
     decoder_forward(d, L, W, rec, params, ws, grid, dec_in, st);
-    if (grid.wide) dvs_launch_loss_fwd_w(dvs_loss_args(d, L, W, rec, params, ws), grid.dags, st);
+    if (grid.wide) dvs_launch_loss_fwd_w(dvs_loss_args(d, L, W, rec, params, ws), grid.dags2, st);
     else if (grid.nw == 4) dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.chain, 4, st);
     else dvs_launch_loss_fwd(dvs_loss_args(d, L, W, rec, params, ws), grid.tiles8, 8, st);
     FinalizeArgs fa;
@@ -871,7 +878,7 @@ extern "C" int dvs_encode(const dvs_shape* s, const void* records, size_t record
     call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs(), is_wide(s));
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
     prepare_images(L, d.N, d.C, is_wide(s), params, ws, W, st);
@@ -904,7 +911,7 @@ extern "C" int dvs_decode(const dvs_shape* s, const float* params, int64_t n_par
     call_begin();
     const DvsDims d = make_dims(s);
     const DvsLayout L = dvs_make_layout(d.N, d.C, nullptr, 0, nullptr);
-    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(d.B, d.NT, L.total, dvs_num_slabs(), is_wide(s));
     float* ws = (float*)workspace;
     dvs_stream_t st = (dvs_stream_t)stream;
     const bool wide = is_wide(s);
@@ -1030,7 +1037,7 @@ extern "C" int dvs_gp_kernel_backward(int32_t na, int32_t nb, int32_t dim, int32
 extern "C" int dvs_debug_activation(const dvs_shape* s, const void* workspace, int slot, float* out, void* stream) {
     if (int e = check_shape(s)) return e;
     const int64_t P = dvs_make_layout(s->n_tokens, s->n_classes, nullptr, 0, nullptr).total;
-    const DvsWorkspace W = dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs());
+    const DvsWorkspace W = dvs_make_workspace(s->batch, tiles_of(s), P, dvs_num_slabs(), is_wide(s));
     const float* ws = (const float*)workspace;
     const float* src = nullptr;
     if (slot >= 0 && slot < DVS_NSLOTS) src = ws + W.act[slot];

@@ -62,6 +62,7 @@ struct AttnBwdArgs {
     float* slab;
     int64_t P;
     int64_t o_out_w, o_out_b;
+    const float* qkv;            // wide path: the forward's q (scaled), k, v (AttnArgs::qkv)
 };
 
 struct LatentBwdArgs {

@@ -62,8 +62,9 @@ struct DvsWorkspace {
     size_t fcpart;              // [DVS_FC_PARTS][P] partial fc1/fc2/fc3 gradients
     size_t wimg;                // per-step weight images (dvs_wimg.h), bf16, written by the forward entry points
     size_t limg;                // per-step latent weight images (dvs_wimg.h: DvsLatImg), fp32, contraction index in frag order
+    size_t qkv[9];              // wide path only: q, k, v of the 9 attention sublayers as the forward parked them, [B NT][12 output tiles][256]
     size_t total_floats;
     int nslab;
 };
 
-DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab);
+DvsWorkspace dvs_make_workspace(int B, int NT, int64_t P, int nslab, bool wide);

@@ -53,6 +53,7 @@ struct AttnArgs {
     float* out_pre;              // x + dropout(attn(x))
     float* out_stats;
     int site_prob, site_post;
+    float* qkv;                  // wide path, optional: q (scaled), k, v of every tile saved for the backward, [B NT][12 output tiles][64 lanes x 4]
 };
 
 struct FfnArgs {

@@ -106,6 +106,7 @@ __device__ __forceinline__ f4 dvs_pair_xchg(const f4& v) {
 constexpr int EMBW_LABLD = DVS_WTOK;             // labw image [32][48]
 struct EmbWLds {
     float *W1, *W2, *labw, *labb;
+    uint32_t* posl;              // [4 waves][16]: the positions (bytes) of the DAG a wave works on (embw_hidden)
 };
 __device__ __forceinline__ EmbWLds embw_lds(char* smem) {
     EmbWLds l;
@@ -113,9 +114,10 @@ __device__ __forceinline__ EmbWLds embw_lds(char* smem) {
     l.W2 = l.W1 + 2 * DVS_WTOK * DVS_LD;         // [64][36]
     l.labw = l.W2 + 64 * EMB_LDW2;               // [32][48]
     l.labb = l.labw + 32 * EMBW_LABLD;
+    l.posl = (uint32_t*)(l.labb + 32);
     return l;
 }
-constexpr size_t EMBW_FLOATS = 2 * DVS_WTOK * DVS_LD + 64 * EMB_LDW2 + 32 * EMBW_LABLD + 32;
+constexpr size_t EMBW_FLOATS = 2 * DVS_WTOK * DVS_LD + 64 * EMB_LDW2 + 32 * EMBW_LABLD + 32 + 4 * 16;
 
 __device__ __forceinline__ void embw_stage(const EmbWLds& l, const EmbedArgs& a) {
     const int N = a.dims.N, C = a.dims.C;
@@ -129,18 +131,24 @@ __device__ __forceinline__ void embw_stage(const EmbWLds& l, const EmbedArgs& a)
 }
 
 // hidden of the positional encoder for token tok0 + r (T-layout), post-ReLU, before dropout; zero for padding rows
-__device__ __forceinline__ void embw_hidden(f4 (&e1)[4], const float* W1, const DvsRecordW* rec, int N, int tok0, int Nl,
-                                            const Lane& L) {
+// posl: this wave's 16 words of EmbWLds::posl — the DAG's positions are copied there first: the walk below reads one per parent,
+// and from global memory every one of them was a dependent load in the chain
+__device__ __forceinline__ void embw_hidden(f4 (&e1)[4], const float* W1, const DvsRecordW* rec, uint32_t* posl, int N, int tok0,
+                                            int Nl, const Lane& L) {
     const bool valid = L.r < Nl;
     const int i = valid ? tok0 + L.r : 0;
-    const float* row = W1 + rec->pos[i] * DVS_LD + 4 * L.g;
+    uint64_t pm = valid ? rec->parents[i] : 0ull;
+    dvs_wave_sync();             // (the wave's previous use of posl is over)
+    if (L.lane < DVS_WTOK / 4) posl[L.lane] = ((const uint32_t*)rec->pos)[L.lane];
+    dvs_wave_sync();
+    const uint8_t* pos = (const uint8_t*)posl;
+    const float* row = W1 + pos[i] * DVS_LD + 4 * L.g;
 #pragma unroll
     for (int t = 0; t < 4; ++t) e1[t] = valid ? *(const f4*)(row + 16 * t) : f4_zero();
-    uint64_t pm = valid ? rec->parents[i] : 0ull;
     while (pm) {
         const int j = dvs_ctz64(pm);
         pm &= pm - 1;
-        const float* prow = W1 + (N + rec->pos[j]) * DVS_LD + 4 * L.g;
+        const float* prow = W1 + (N + pos[j]) * DVS_LD + 4 * L.g;
 #pragma unroll
         for (int t = 0; t < 4; ++t) e1[t] += *(const f4*)(prow + 16 * t);
     }
@@ -176,11 +184,14 @@ __device__ __forceinline__ LossWLds lossw_lds(char* smem) {
     l.pV = l.pU + 4 * DVS_SCR;                  // likewise dV
     return l;
 }
-static inline size_t dvs_lossw_lds_floats(bool backward = true) {       // forward: no parked dU / dV blocks
-    return (backward ? 0 : -8 * (ptrdiff_t)DVS_SCR) + 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128 + 2 * (size_t)DVS_WSCR +
-           DVS_WTOK * (DVS_WTOK + 1) + 16 + 12 * (size_t)DVS_SCR;
+// forward: the images, V and 16 floats of per-wave partial sums (in the first words of what is U in the backward) — 65 KB, two
+// workgroups per CU (the kernel runs 3 of its 4 waves at N = 40, one per SIMD: it is latency-bound)
+static inline size_t dvs_lossw_lds_floats(bool backward = true) {
+    const size_t head = 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128;
+    if (!backward) return head + (size_t)DVS_WSCR + 16;
+    return head + 2 * (size_t)DVS_WSCR + DVS_WTOK * (DVS_WTOK + 1) + 16 + 12 * (size_t)DVS_SCR;
 }
-__device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a) {
+__device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a, bool backward = true) {
     const int C = a.dims.C;
     dvs_stage_matrix(l.Wn1, DVS_LD, a.node0_w, 64, 32, 64);
     for (int i = threadIdx.x; i < DVS_WTOK * 32; i += blockDim.x) {
@@ -196,7 +207,7 @@ __device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a
     if (threadIdx.x == 0) l.b2[0] = a.edge2_b[0];
     dvs_stage_vector(l.lg, a.ln.g, 64);
     dvs_stage_vector(l.lb, a.ln.b, 64);
-    for (int i = threadIdx.x; i < 2 * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
+    for (int i = threadIdx.x; i < (backward ? 2 : 1) * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
 }
 // backward only: the per-wave transpose tiles and the parked dU / dV blocks start as zeros (blocks of tiles the DAG does not
 // have — tile 3 always — are never written and are contracted as they are)

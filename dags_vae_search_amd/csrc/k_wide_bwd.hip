@@ -19,30 +19,28 @@
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATTNWB_TLD = 20;                   // floats per row of a transposing scratch tile (16 + 4: 16-byte rows, 2-way banks at most)
 constexpr int ATTNWB_TSCR = 2 * 16 * ATTNWB_TLD; // per wave: dS and P' tiles of the current pair (attnwb_core)
+// Two sets of {Q, K, V, dO} ([48][DVS_LD] fp32 each): the core works on one while the waves the tail leaves idle fill the other
+// with the workgroup's next DAG.  No in-projection images: q, k, v are read back from the forward (AttnArgs::qkv).
 struct AttnWBLds {
-    dvs_bf16 *WoTh, *WoTl, *Winh, *Winl;     // bf16x3 pairs, in the order of the per-step block (dvs_wimg.h: WoutT, WinB)
-    float *inb, *outb, *lg, *lb, *Q, *K, *V, *DO, *tscr;      // Q / K / V / dO end the core as dq / dk / dv / O (attnwb_core)
-    uint64_t* al;                // [48] ancestor bit-rows (whom token i attends)
+    dvs_bf16 *WoTh, *WoTl;       // bf16x3 pair of Wo^T (dvs_wimg.h: WoutT)
+    float *outb, *Q, *K, *V, *DO, *tscr;      // Q / K / V / dO of the CURRENT set; they end the core as dq / dk / dv / O (attnwb_core)
+    uint64_t* al;                // [48] ancestor bit-rows (whom token i attends) of the current set
 };
-__device__ __forceinline__ AttnWBLds attnwb_lds(char* smem) {
+constexpr size_t ATTNWB_SET = 4 * (size_t)DVS_WSCR;      // floats of one buffer set
+__device__ __forceinline__ AttnWBLds attnwb_lds(char* smem, int set) {
     AttnWBLds l;
     l.WoTh = (dvs_bf16*)smem;
     l.WoTl = l.WoTh + 64 * DVS_LDB;
-    l.Winh = l.WoTl + 64 * DVS_LDB;
-    l.Winl = l.Winh + 192 * DVS_LDB;
-    l.inb = (float*)(l.Winl + 192 * DVS_LDB);
-    l.outb = l.inb + 192;
-    l.lg = l.outb + 64;
-    l.lb = l.lg + 64;
-    l.Q = l.lb + 64;
+    l.outb = (float*)(l.WoTl + 64 * DVS_LDB);
+    l.Q = l.outb + 64 + set * ATTNWB_SET;
     l.K = l.Q + DVS_WSCR;
     l.V = l.K + DVS_WSCR;
     l.DO = l.V + DVS_WSCR;
-    l.tscr = l.DO + 2 * DVS_WSCR;                // (two dO buffers: k_attn_bwd_w) [8 waves][2][16][ATTNWB_TLD]
-    l.al = (uint64_t*)(l.tscr + 8 * ATTNWB_TSCR);   // (offset is a multiple of 8 bytes)
+    l.tscr = l.outb + 64 + 2 * ATTNWB_SET;       // [8 waves][2][16][ATTNWB_TLD]
+    l.al = (uint64_t*)(l.tscr + 8 * ATTNWB_TSCR) + set * DVS_WTOK;   // (offset is a multiple of 8 bytes)
     return l;
 }
-constexpr size_t ATTNWB_FLOATS = 8 * DVS_IMG64 / 2 + 192 + 64 + 128 + 5 * (size_t)DVS_WSCR + 8 * ATTNWB_TSCR + 2 * DVS_WTOK;
+constexpr size_t ATTNWB_FLOATS = 2 * DVS_IMG64 / 2 + 64 + 2 * ATTNWB_SET + 8 * ATTNWB_TSCR + 2 * 2 * DVS_WTOK;
 static_assert(ATTNWB_FLOATS * 4 <= 160 * 1024, "k_attn_bwd_w LDS");
 
 
@@ -132,14 +130,9 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
     f4 dk[DVS_WNT], dv[DVS_WNT];
 #pragma unroll
     for (int jt = 0; jt < DVS_WNT; ++jt) dk[jt] = dv[jt] = f4_zero();
-    // the two waves of a SIMD (heads h and h + 4) walk the query tiles in opposite directions: a late tile has more key tiles,
-    // so the softmax arithmetic of one wave falls on the MFMA chains of the other instead of both colliding on the same pipe
-    for (int ii = 0; ii < NT; ++ii) {
-#ifdef DVS_WB_NOREV
-        const int it = ii;
-#else
-        const int it = h >= 4 ? NT - 1 - ii : ii;
-#endif
+    // (walking the query tiles in opposite directions on the two waves of a SIMD, so that one's softmax arithmetic meets the
+    // other's MFMA chains: measured +1.5 % — the older wave runs ahead anyway)
+    for (int it = 0; it < NT; ++it) {
         const int i = 16 * it + L.r;
         const uint64_t row = l.al[i];
         float fq[2], fg[2];
@@ -148,17 +141,22 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
         const f4 qc = attnwb_col(l.Q, it, c0, L), gc = attnwb_col(l.DO, it, c0, L);     // for dk, dv: this tile's rows are overwritten below
         f4 sT[DVS_WNT], dpT[DVS_WNT];
         float m = -3.0e38f;
+        // every key tile's row fragments in one batch of LDS reads (rows of tiles the DAG does not have are zeros): one wait for
+        // the tile's score products instead of one per pair — the core is a chain of LDS and MFMA latencies on two waves per SIMD
+        float fk[DVS_WNT][2], fv[DVS_WNT][2];
+#pragma unroll
+        for (int jt = 0; jt < DVS_WNT; ++jt) {
+            attnwb_row(fk[jt], l.K, jt, c0, L);
+            attnwb_row(fv[jt], l.V, jt, c0, L);
+        }
 #pragma unroll
         for (int jt = 0; jt < DVS_WNT; ++jt) {
             sT[jt] = dpT[jt] = f4_zero();
             if (!((pairs >> (3 * it + jt)) & 1u)) continue;
-            float fk[2], fv[2];
-            attnwb_row(fk, l.K, jt, c0, L);
-            attnwb_row(fv, l.V, jt, c0, L);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sT[jt] = dvs_mfma(fk[s], fq[s], sT[jt]);
-                dpT[jt] = dvs_mfma(fv[s], fg[s], dpT[jt]);
+                sT[jt] = dvs_mfma(fk[jt][s], fq[s], sT[jt]);
+                dpT[jt] = dvs_mfma(fv[jt][s], fg[s], dpT[jt]);
             }
             const uint32_t ok4 = (uint32_t)(row >> (16 * jt + 4 * L.g)) & 0xFu;
 #pragma unroll
@@ -201,17 +199,15 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
             for (int reg = 0; reg < 4; ++reg) ds[reg] = sT[jt][reg] * (dpT[jt][reg] - delta);
             attnwb_put(tscr, ds, L);
             attnwb_put(tscr + 16 * ATTNWB_TLD, pmk[jt], L);
-            const f4 kc = attnwb_col(l.K, jt, c0, L), vc = attnwb_col(l.V, jt, c0, L);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                dq = dvs_mfma(kc[reg], ds[reg], dq);
-                o = dvs_mfma(vc[reg], pmk[jt][reg], o);
-            }
             dvs_wave_sync();
+            // all four operands of the pair in one batch of reads, then four independent MFMA chains interleaved
+            const f4 kc = attnwb_col(l.K, jt, c0, L), vc = attnwb_col(l.V, jt, c0, L);
             const f4 dsS = attnwb_get(tscr, L), pS = attnwb_get(tscr + 16 * ATTNWB_TLD, L);       // (query 4g + reg, key r)
             dvs_wave_sync();
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
+                dq = dvs_mfma(kc[reg], ds[reg], dq);
+                o = dvs_mfma(vc[reg], pmk[jt][reg], o);
                 dk[jt] = dvs_mfma(qc[reg], dsS[reg], dk[jt]);
                 dv[jt] = dvs_mfma(gc[reg], pS[reg], dv[jt]);
             }
@@ -236,53 +232,72 @@ __device__ __forceinline__ void attnwb_core(const AttnWBLds& l, int h, int N, in
     }
 }
 
-// dO^T = Wo^T dropout-mask(d pre) of DAG `dag`, parked in `DO`: the 4 NT output tiles (unit u = 4 tile + ot) are shared by the
-// `nw` waves that take part (wave index wi), every wave inside ONE token tile (a tile costs a load, the dropout draws and the
-// bf16 split before its first product).
-__device__ __forceinline__ void attnwb_do_job(const AttnWBLds& l, float* DO, const AttnBwdArgs& a, int dag, int wi, int nw,
-                                              const DvsDrop& D, const Lane& L) {
-    const int N = a.dims.N, NT = a.dims.NT;
-    const int per = nw < 2 * NT ? 4 : (nw < 4 * NT ? 2 : 1);
-    const int u0 = wi * per, u1 = (u0 + per < 4 * NT) ? u0 + per : 4 * NT;
-    if (u0 >= u1) return;
-    const int tw = u0 >> 2;
-    const uint32_t gdag = a.dims.dag_offset + dag;
-    f4 dyt[4];
-    dvs_load_grad(dyt, a.gpre, (size_t)dag * NT + tw, dvs_rows_of(N, tw), L);
-    dvs_dropout_tile(dyt, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, 16 * tw);
-    const SplitT ds = dvs_split_T(dyt);
-    for (int u = u0; u < u1; ++u) {
-        const int ot = u & 3;
-        f4 o1[1] = {f4_zero()};
-        dvs_matb_T<1>(o1, ds, l.WoTh, l.WoTl, 16 * ot, L);
-        dvs_park_col(DO, 16 * tw, ot, o1[0], L);
+// Fill one buffer set with DAG `dag`: q (scaled), k, v as the forward parked them (AttnArgs::qkv: one 16-byte load per lane and
+// output tile, unit u = 12 tile + o12, o12: 0-3 q, 4-7 k, 8-11 v), dO^T = Wo^T dropout-mask(d pre) (bf16x3: a gradient product,
+// as in the one-tile backward), the DAG's ancestor rows.  `nw` waves take part (wave index wi): every wave issues the loads of
+// its share of the q / k / v units first, the first NT of them then compute the dO tile of one token tile each (a tile costs a
+// load, the dropout draws and the bf16 split before its first product) — the loads land meanwhile —, then the units are parked.
+constexpr int ATTNWB_MAXU = 8;                   // q / k / v units per wave and batch
+__device__ __forceinline__ void attnwb_fill(const AttnWBLds& l, const AttnBwdArgs& a, int dag, int wi, int nw, const DvsDrop& D,
+                                            const Lane& L, unsigned long long& wst_) {
+    const int N = a.dims.N, NT = a.dims.NT, nunits = 12 * NT;
+    if (wi == nw - 1 && L.lane < DVS_WTOK) {
+        const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
+        l.al[L.lane] = L.lane < N ? rec->allowed[L.lane] : 0ull;
+    }
+    const f4* src = (const f4*)(a.qkv + (size_t)dag * NT * 12 * 256) + L.lane;
+    for (int u0 = wi; u0 < nunits; u0 += nw * ATTNWB_MAXU) {
+        f4 v[ATTNWB_MAXU];
+#pragma unroll
+        for (int k = 0; k < ATTNWB_MAXU; ++k) {
+            const int u = u0 + k * nw;
+            v[k] = src[(size_t)(u < nunits ? u : u0) * 64];
+        }
+        WBSTAMP(1);
+        if (u0 == wi && wi < NT) {               // (first batch only) this wave's token tile of dO
+            const int tw = wi;
+            const uint32_t gdag = a.dims.dag_offset + dag;
+            f4 dyt[4];
+            dvs_load_grad(dyt, a.gpre, (size_t)dag * NT + tw, dvs_rows_of(N, tw), L);
+            dvs_dropout_tile(dyt, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_post, gdag), D, L, 16 * tw);
+            const SplitT ds = dvs_split_T(dyt);
+            f4 o4[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+            dvs_matb_T<4>(o4, ds, l.WoTh, l.WoTl, 0, L);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) dvs_park_col(l.DO, 16 * tw, ot, o4[ot], L);
+        }
+        WBSTAMP(2);
+#pragma unroll
+        for (int k = 0; k < ATTNWB_MAXU; ++k) {
+            const int u = u0 + k * nw;
+            if (u < nunits) {
+                const int t = u / 12, o12 = u - 12 * t;
+                dvs_park_col(l.Q + (o12 >> 2) * DVS_WSCR, 16 * t, o12 & 3, v[k], L);       // Q, K, V are consecutive
+            }
+        }
     }
 }
 
-// 8 waves.  Per DAG:
-//   stage 1 : q, k, v of every tile (bf16x3 from the per-step images: q, k, v feed a softmax — smooth, as in the one-tile
-//             backward), the 12 NT output tiles shared evenly by the eight waves, parked in LDS                | barrier
-//   core    : wave h = head h (attnwb_core)                                                                   | barrier
-//   tail    : waves 0..NT-1 own the tiles: store dq, dk, dv, park d y and O as bf16 pairs | barrier | waves 0..3: dWo += dy^T O
-//             cooperatively.  Waves 4..7 have no part in that: they compute dO^T of the workgroup's NEXT DAG into the other
-//             of two dO buffers (the first DAG's is computed by all waves ahead of the loop)                    | barrier
-// Round 3's first version computed dO inside stage 1 on two waves, which then took 10.1 k cycles against 5.3-6.5 k of the six
-// projection waves, while waves 4-7 idled through the 4.7 k of the tail (`profiles/r03_wide_stamps_bwd.txt`).
+// 8 waves, two DAGs in flight per workgroup.  Per DAG:
+//   core    : wave h = head h on the current buffer set (attnwb_core)                                               | barrier
+//   tail 1  : waves 0..NT-1 own the tiles: store dq, dk, dv, park d y and O as bf16 pairs;
+//             waves NT..7 fill the OTHER buffer set with the workgroup's next DAG (attnwb_fill)                    | barrier
+//   tail 2  : waves 0..3: dWo += dy^T O cooperatively                                                              | barrier
+// Nothing but LDS traffic and MFMAs sits between two cores of a workgroup besides the tile owners' stores: the loads of the next
+// DAG have the whole tail to land.  Round 3's first versions recomputed q, k, v from the sublayer input inside a stage of its
+// own (5-7 k cycles per DAG on six waves, dO on the other two 10 k, then the core, then a tail that left five waves idle:
+// 41.9 k cycles per DAG, `profiles/r03_wide_stamps_bwd.txt`); with the in-projection images gone (55 KB) the second buffer set
+// fits LDS.
 __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     DVS_DYN_LDS(smem);
     unsigned long long wst_ = 0;
 #ifdef DVS_STAMPS
     wst_ = __builtin_amdgcn_s_memtime();
 #endif
-    const AttnWBLds l = attnwb_lds(smem);
-    dvs_copy_image(l.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(8 * DVS_IMG64));     // WoutT pair, Win hi / mid
-    dvs_stage_vector(l.inb, a.in_b, 192);
-    dvs_stage_vector(l.outb, a.out_b, 64);
-    if (a.ln.stats) {
-        dvs_stage_vector(l.lg, a.ln.g, 64);
-        dvs_stage_vector(l.lb, a.ln.b, 64);
-    }
-    for (int i = threadIdx.x; i < 5 * DVS_WSCR; i += blockDim.x) l.Q[i] = 0.f;
+    const AttnWBLds l0 = attnwb_lds(smem, 0);
+    dvs_copy_image(l0.WoTh, (const dvs_bf16*)a.wimg + DvsAttnImg::WoutT, (int)(2 * DVS_IMG64));     // WoutT pair
+    dvs_stage_vector(l0.outb, a.out_b, 64);
+    for (int i = threadIdx.x; i < (int)(2 * ATTNWB_SET); i += blockDim.x) l0.Q[i] = 0.f;
     __syncthreads();
     const Lane L = dvs_lane();
     const DvsDrop D = dvs_drop_of(a.dims);
@@ -294,88 +309,40 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
     // 16 accumulator registers per wave instead of 64 (all eight waves would carry them through the core)
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, abo = f4_zero();
     int cur = 0;
-    if ((int)blockIdx.x < B) attnwb_do_job(l, l.DO, a, blockIdx.x, L.wave, 8, D, L);
     WBSTAMP(0);
-    for (int dag = blockIdx.x; dag < B; dag += gridDim.x) {
-        const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
-        const size_t tile = (size_t)dag * NT + L.wave;
+    // the first pass (dag < 0) only fills the other buffer set with the workgroup's first DAG: one copy of every stage's code
+    for (int dag = (int)blockIdx.x - (int)gridDim.x; dag < B; dag += gridDim.x) {
+        const bool real = dag >= 0;
+        const size_t tile = (size_t)(real ? dag : 0) * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
-        AttnWBLds lc = l;
-        lc.DO = l.DO + cur * DVS_WSCR;
-        float* const DOnext = l.DO + (cur ^ 1) * DVS_WSCR;
-        if (threadIdx.x >= 256 && threadIdx.x < 256 + DVS_WTOK) {
-            const int i = threadIdx.x - 256;
-            l.al[i] = i < N ? rec->allowed[i] : 0ull;
-        }
-        // ---- stage 1: output tile u = 12 tile + o12 (o12: 0-3 q of x, 4-7 k and 8-11 v of the key / value input) ----------
-        {
-            const int nunits = 12 * NT;
-            int u = nunits * L.wave / 8;
-            const int u1 = nunits * (L.wave + 1) / 8;
-            int ct = -1;
-            SplitT xs, kvs;
-            for (; u < u1; ++u) {
-                const int t = u / 12, o12 = u - 12 * t;
-                if (t != ct) {               // (a wave's range crosses at most one tile boundary)
-                    ct = t;
-                    const size_t ptile = (size_t)dag * NT + t;
-                    f4 x[4], dummy[4];
-                    float rstd;
-                    dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, ptile, dvs_rows_of(N, t), L);
-                    xs = dvs_split_T(x);
-                    if (a.kv) {
-                        f4 kv[4];
-                        dvs_load_tile(kv, a.kv, ptile, L);
-                        kvs = dvs_split_T(kv);
-                    } else {
-                        kvs = xs;
-                    }
-                }
-                f4 o1[1] = {dvs_vecT(l.inb + 16 * o12, 0, L)};
-                if (o12 < 4) dvs_matb_T<1>(o1, xs, l.Winh, l.Winl, 16 * o12, L);
-                else dvs_matb_T<1>(o1, kvs, l.Winh, l.Winl, 16 * o12, L);
-                float* const buf = o12 < 4 ? l.Q : (o12 < 8 ? l.K : l.V);
-                dvs_park_col(buf, 16 * t, o12 & 3, o12 < 4 ? o1[0] * scale : o1[0], L);
-            }
-        }
-        WBSTAMP(1);
-        __syncthreads();
-        WBSTAMP(2);
-        // every wave touches the tiles it loads next — the workgroup's next DAG's stage-1 inputs, the d pre tile of the tail —
-        // ahead of the core, one 4-byte load per lane and tile (a lane per 64 bytes: every line of the tile), kept in a register
-        // until the core is over: the tiles arrive in the cache while the core runs on LDS only (as dvs_touch_first does between
-        // the phases of the chained kernels; stage 1 and the tail were 30-50 % cold-load latency)
-        float tch[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        {
-            const int nd = dag + (int)gridDim.x;
-            const size_t loff = (size_t)L.lane * 16;
-            if (nd < B) {
-                const int nunits = 12 * NT;
-                const size_t ta = (size_t)nd * NT + (nunits * L.wave / 8) / 12, tb = (size_t)nd * NT + (nunits * (L.wave + 1) / 8 - 1) / 12;
-                tch[0] = a.xin[ta * 1024 + loff];
-                tch[1] = a.xin[tb * 1024 + loff];
-                if (a.kv) {
-                    tch[2] = a.kv[ta * 1024 + loff];
-                    tch[3] = a.kv[tb * 1024 + loff];
-                }
-            }
+        const AttnWBLds l = attnwb_lds(smem, cur);
+        if (real) {
+            // the tile owners touch their d pre tile of the tail ahead of the core (one 4-byte load per lane: every line of the tile)
+            // ... and the other waves every line of what they load for the next DAG in the tail (attnwb_fill: this wave's q / k / v
+            // units, 8 lines of 128 bytes each — lane = (unit, line) —, and its d pre tile): a cold load costs 4-7 k cycles here,
+            // more than the tail lasts; behind the touches the tail's loads hit the cache
+            float tch = 0.f, tch2 = 0.f;
             if (has_tile) {
-                tch[4] = a.gpre[tile * 1024 + loff];
-            } else if (L.wave >= 4 && nd < B) {
-                const int per = 4 < 2 * NT ? 4 : 2, u0 = (L.wave - 4) * per;       // attnwb_do_job with 4 waves
-                if (u0 < 4 * NT) tch[4] = a.gpre[((size_t)nd * NT + (u0 >> 2)) * 1024 + loff];
+                tch = a.gpre[tile * 1024 + (size_t)L.lane * 16];
+            } else if (dag + (int)gridDim.x < B) {
+                const int nd = dag + (int)gridDim.x, wi = L.wave - NT, nw = 8 - NT, nunits = 12 * NT;
+                int u = wi + (L.lane >> 3) * nw;
+                u = u < nunits ? u : wi;
+                tch = a.qkv[((size_t)nd * NT * 12 + u) * 256 + (L.lane & 7) * 32];
+                if (wi < NT) tch2 = a.gpre[((size_t)nd * NT + wi) * 1024 + (size_t)L.lane * 16];
             }
-        }
-        // ---- core: wave h = head h, on the matrix pipe (attnwb_core above) ----------------------------------------------
-        attnwb_core(lc, L.wave, N, NT, kprob, D, scale, L, wst_);
+            // ---- core: wave h = head h, on the matrix pipe (attnwb_core above) ------------------------------------------
+            attnwb_core(l, L.wave, N, NT, kprob, D, scale, L, wst_);
 #ifndef DVS_EMU
-        asm volatile("" ::"v"(tch[0]), "v"(tch[1]), "v"(tch[2]), "v"(tch[3]), "v"(tch[4]));
+            asm volatile("" ::"v"(tch), "v"(tch2));
 #endif
+        }
         WBSTAMP(4);
         __syncthreads();
         WBSTAMP(5);
-        if (has_tile) {
+        if (!real) {
+        } else if (has_tile) {
             const bool valid = L.r < Nl;
             f4 dy[4];                 // this tile's masked d pre again, for dWo / dbo
             dvs_load_grad(dy, a.gpre, tile, Nl, L);
@@ -396,18 +363,17 @@ __global__ __launch_bounds__(512) void k_attn_bwd_w(AttnBwdArgs a) {
             // dWo += dy^T O, dbo += column sums of dy: both tiles parked as bf16 [hi | lo] pairs for the cooperative product
             // below — d y over this tile's rows of Q (free now), O converted in place (a pair is exactly the 16 fp32 rows it replaces)
             f4 o[4];
-            dvs_lds_T(o, lc.DO, tok0, L);                // O (in place)
+            dvs_lds_T(o, l.DO, tok0, L);                 // O (in place)
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = valid ? o[t] : f4_zero();
             dvs_wave_sync();
             dvs_park_bf((dvs_bf16*)(l.Q + tok0 * DVS_LD), dy, L);
-            dvs_park_bf((dvs_bf16*)(lc.DO + tok0 * DVS_LD), o, L);
-        } else if (L.wave >= 4 && dag + (int)gridDim.x < B) {
-            attnwb_do_job(l, DOnext, a, dag + gridDim.x, L.wave - 4, 4, D, L);
+            dvs_park_bf((dvs_bf16*)(l.DO + tok0 * DVS_LD), o, L);
         }
+        if (!has_tile && dag + (int)gridDim.x < B) attnwb_fill(attnwb_lds(smem, cur ^ 1), a, dag + gridDim.x, L.wave - NT, 8 - NT, D, L, wst_);
         WBSTAMP(6);
         __syncthreads();
-        if (L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)lc.DO, NT, L);
+        if (real && L.wave < 4) dvsw_coop_dw(aWo, abo, (const dvs_bf16*)l.Q, (const dvs_bf16*)l.DO, NT, L);
         __syncthreads();
         WBSTAMP(7);
         cur ^= 1;
@@ -723,26 +689,28 @@ __global__ __launch_bounds__(256) void k_embed_bwd_w(EmbedArgs a, const float* g
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
         const uint32_t gdag = a.dims.dag_offset + dag;
-        if (threadIdx.x < DVS_WTOK) {
-            const int p = threadIdx.x;
-            uint64_t pm = 0, lm = 0;
-            for (int i = 0; i < N; ++i) {
-                if (rec->pos[i] == p) pm |= 1ull << i;
-                if (rec->label[i] == p) lm |= 1ull << i;
+        // the DAG's masks, one ballot each over lane = token (wave w: p = w, w + 4, ..): round 3's first version had thread p walk
+        // the record's bytes in global memory, 2 N dependent loads per DAG ahead of everything else
+        {
+            const int ti = L.lane < N ? L.lane : 0;
+            const int mypos = L.lane < N ? (int)rec->pos[ti] : -1, mylab = L.lane < N ? (int)rec->label[ti] : -1;
+            const uint64_t mypar = L.lane < N ? rec->parents[ti] : 0ull;
+            if (L.wave == 0 && L.lane < DVS_WTOK) parents[L.lane] = mypar;
+            for (int p = L.wave; p < DVS_WTOK; p += 4) {
+                const uint64_t pm = __ballot(mypos == p), lm = __ballot(mylab == p);
+                const uint64_t qm = __ballot((mypar & pm) != 0ull);
+                if (L.lane == 0) {
+                    posmask[p] = pm;
+                    parmask[p] = qm;
+                    labmask[p] = lm;
+                }
             }
-            uint64_t qm = 0;
-            for (int i = 0; i < N; ++i)
-                if (rec->parents[i] & pm) qm |= 1ull << i;
-            posmask[p] = pm;
-            parmask[p] = qm;
-            labmask[p] = lm;
-            parents[p] = p < N ? rec->parents[p] : 0ull;
         }
         if (has_tile) {
             const bool valid = L.r < Nl;
             const int label = rec->label[valid ? tok0 + L.r : 0];
             f4 e1[4];
-            embw_hidden(e1, l.W1, rec, N, tok0, Nl, L);
+            embw_hidden(e1, l.W1, rec, l.posl + 16 * L.wave, N, tok0, Nl, L);
             f4 de1s[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()}, dles[2] = {f4_zero(), f4_zero()};
             for (int src = 0; src < 2; ++src) {
                 const float* gsrc = src == 0 ? a.gout : gout2;

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_embed_fwd_w(EmbedArgs a) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + T.dag;
         const bool valid = L.r < T.Nl;
         f4 e1[4];
-        embw_hidden(e1, l.W1, rec, N, T.tok0, T.Nl, L);
+        embw_hidden(e1, l.W1, rec, l.posl + 16 * L.wave, N, T.tok0, T.Nl, L);
         const uint32_t gdag = a.dims.dag_offset + T.dag;
         dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site, gdag), D, L, T.tok0);
         f4 x[4];
@@ -371,6 +371,13 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                 for (int t = 0; t < 4; ++t) dvs_park_col(l.Q, ptok0, t, q[t] * scale, L);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, t, k01[t], L);
+                if (a.qkv) {          // the backward reads q, k, v back instead of recomputing them (k_attn_bwd_w): 1 KB per output tile
+                    f4* sv = (f4*)(a.qkv + tile * 12 * 256) + L.lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sv[t * 64] = q[t] * scale;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) sv[(4 + t) * 64] = k01[t];
+                }
             } else {
                 f4 k23[2], v[4];
 #pragma unroll
@@ -383,6 +390,13 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
                 for (int t = 0; t < 2; ++t) dvs_park_col(l.K, ptok0, 2 + t, k23[t], L);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dvs_park_col(l.V, ptok0, t, v[t], L);
+                if (a.qkv) {
+                    f4* sv = (f4*)(a.qkv + tile * 12 * 256) + L.lane;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) sv[(6 + t) * 64] = k23[t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sv[(8 + t) * 64] = v[t];
+                }
             }
         }
         WSTAMP(1);
@@ -549,7 +563,8 @@ void dvs_launch_attn_fwd_w(const AttnArgs& a, int grid, dvs_stream_t st) {
 __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
     DVS_DYN_LDS(smem);
     const LossWLds l = lossw_lds(smem);
-    lossw_stage(l, a);
+    lossw_stage(l, a, false);
+    float* const part = l.U;                              // (forward layout: dvs_lossw_lds_floats(false))
     __syncthreads();
     const Lane L = dvs_lane();
     const int N = a.dims.N, C = a.dims.C, NT = a.dims.NT;
@@ -634,12 +649,12 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
             }
             nll += (L.g == 0) ? enll : 0.f;
             nll = dvs_sum_wave(nll);
-            if (L.lane == 0) l.part[L.wave] = nll;
+            if (L.lane == 0) part[L.wave] = nll;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             float s = 0.f;
-            for (int w = 0; w < NT; ++w) s += l.part[w];
+            for (int w = 0; w < NT; ++w) s += part[w];
             a.dag_loss[(size_t)dag * 2] = s;
         }
     }

@@ -22,7 +22,7 @@ train_batch(f, model, opt); torch.cuda.synchronize()
 fn(buf.ctypes.data, buf.nbytes, 0)
 t = buf.reshape(256, 8, 8).astype(np.float64) / (9 * 8)     # 9 launches x 8 DAGs per workgroup
 if which == "bwd":
-    print("k_attn_bwd_w, cycles per DAG (mean over WGs): 0 prologue(per launch/72) 1 stage1 2 barrier 3 core T pass 4 core S pass 5 barrier 6 stores / parks 7 barrier + dWo + barrier")
+    print("k_attn_bwd_w, cycles per DAG (mean over WGs): 0 prologue(per launch/72) 1 fill: loads issued 2 fill: dO tile 3 core 4 (core end) 5 barrier 6 stores + parks | fill: q / k / v parked 7 barrier + dWo + barrier")
     for w in range(8): print("wave", w, np.round(t[:, w, :8].mean(0)).astype(int).tolist(), "sum", int(t[:, w, 1:8].mean(0).sum()))
 else:
     print("k_attn_fwd_w, cycles per DAG (mean over WGs): k: 0 prologue(per launch/72) 1 stage1 2 barrier 3 stage2 4 barrier 5 stage3 6 barrier")

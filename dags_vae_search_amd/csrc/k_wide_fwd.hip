@@ -409,6 +409,17 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
             float rstd;
             dvs_load_x<false>(x, dummy, rstd, a.xin, a.ln, l.lg, l.lb, (size_t)dag * NT + L.wave, Nl, L);
         }
+        // the projection waves touch their input tile(s) of the workgroup's NEXT DAG ahead of the core (one 4-byte load per lane:
+        // every line of the tile; consumed behind the core): stage 1 opened with a cold load (4-7 k cycles on this machine).
+        // Measured: k_attn_fwd_w 78.2 -> 76.6 us.  (Tried and dropped, `gpurun_out/r03_ab_alarm1{6,8}.txt`: k / v of the next DAG
+        // projected by the waves stage 3 leaves idle (+5 %: five waves need 7.9 k cycles for them, stage 3 lasts 3.6 k), stage 1
+        // spread over all eight waves (no change: the stage is not bound by the output tiles per wave).)
+        float tch0 = 0.f, tch1 = 0.f;
+        if (proj && dag + (int)gridDim.x < a.dims.B) {
+            const size_t nt = ((size_t)(dag + gridDim.x) * NT + pw) * 1024 + (size_t)L.lane * 16;
+            tch0 = a.xin[nt];
+            if (a.kv) tch1 = a.kv[nt];
+        }
         // ---- stage 2: head h of every query tile ---------------------------------------------------------------------
         const uint32_t kprob = dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site_prob, gdag);
         // All NT query tiles in one unrolled pass: their chains (LDS reads -> 2 + 4 dependent MFMAs per key tile -> shuffles
@@ -527,6 +538,9 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
 #pragma unroll
         for (int it = 0; it < DVS_WNT; ++it)
             if (it < NT && mine) *(f4*)(l.Q + (16 * it + L.r) * DVS_LD + 16 * hp + 4 * L.g) = o[it];   // O over this head's slice of Q
+#ifndef DVS_EMU
+        asm volatile("" ::"v"(tch0), "v"(tch1));
+#endif
         WSTAMP(3);
         __syncthreads();
         WSTAMP(4);

@@ -62,8 +62,27 @@ extern "C" int dvs_debug_read_stamps_wb(void* out, size_t bytes, int clear) {
     }
     return 0;
 }
+// ... and of the two head kernels: ids 0-3 k_embed_bwd_w (tile stage, barrier, scatters, barrier), 4-7 k_loss_bwd_w (heads + U / V,
+// pass 1 incl. barrier, pass 2 incl. barrier, edge matrices + d h + store incl. barrier)
+__device__ unsigned long long dvs_stamps_wc[256 * 8 * 8];
+#define WCSTAMP(k)                                                                                          \
+    do {                                                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) dvs_stamps_wc[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] += now_ - wst_; \
+        wst_ = now_;                                                                                        \
+    } while (0)
+extern "C" int dvs_debug_read_stamps_wc(void* out, size_t bytes, int clear) {
+    if (bytes > sizeof(dvs_stamps_wc)) bytes = sizeof(dvs_stamps_wc);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dvs_stamps_wc), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dvs_stamps_wc)) != hipSuccess || hipMemset(p, 0, sizeof(dvs_stamps_wc)) != hipSuccess) return 2;
+    }
+    return 0;
+}
 #else
 #define WBSTAMP(k) ((void)0)
+#define WCSTAMP(k) ((void)0)
 #endif
 
 // ---- MFMA core of the wide attention backward ----------------------------------------------------------------------------
@@ -442,6 +461,10 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
         dbn2[i] = f4_zero();
         dWn2[i][0] = dWn2[i][1] = f4_zero();
     }
+    unsigned long long wst_ = 0;
+#ifdef DVS_STAMPS
+    wst_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
@@ -525,6 +548,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             dvs_park_T(l.V + tok0 * DVS_LD, V, L);
             dvs_park_T(l.U + tok0 * DVS_LD, U, L);
         }
+        WCSTAMP(4);
         __syncthreads();
         if (has_tile) {
             // pass 1: lane r = token i walks j < i; accumulates dU, dw2, db2; publishes d logit(i, j)
@@ -563,6 +587,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) dU[t] = w2v[t] * sU[t];
         }
+        WCSTAMP(5);
         __syncthreads();
         if (has_tile) {
             // pass 2: lane r = token j walks i > j; accumulates dV
@@ -585,6 +610,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             dvs_park_bf(pV + L.wave * 2 * DVS_SCR, dV, L);
             dvs_park_bf((dvs_bf16*)scr, h, L);                        // the wave's transpose tile is free by now
         }
+        WCSTAMP(6);
         __syncthreads();
         dvsw_coop_dw(aWa, abU, pU, (const dvs_bf16*)l.scr, NT, L);   // all four waves (wave 3 has no tile but owns rows 48..63)
         dvsw_coop_dw(aWb, abV, pV, (const dvs_bf16*)l.scr, NT, L);
@@ -595,6 +621,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             dvs_store_tile(a.gout, tile, dh, L);
         }
         __syncthreads();
+        WCSTAMP(7);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
@@ -674,17 +701,24 @@ __global__ __launch_bounds__(256) void k_embed_bwd_w(EmbedArgs a, const float* g
     const int tok0 = 16 * L.wave, Nl = dvs_rows_of(N, L.wave);
     const bool has_tile = L.wave < NT;
     float* scr = scr0 + L.wave * DVS_SCR;
-    float aW1[EMBW_W1_PER_THREAD], alab[EMBW_LAB_PER_THREAD];
+    // d W1 ([2 N][64]: rows p < N <- tokens at position p, rows N + p <- tokens with parents at position p, once per parent) and
+    // the label table's gradient ([C classes][32]) as products with 0 / count selector matrices on the matrix pipe, as the
+    // one-tile kernel does: wave w owns feature tile w of d W1 (6 row tiles of 16 positions) and label tiles w, w + 4 of the six
+    // (3 class tiles x 2 feature tiles).  A operand element [row p][token i] = popcount(mask_p & sel_i): sel_i = bit i for a
+    // position row, the parent row of token i for a parent row.  (Round 3's first version was owner-computes: thread (row, feature)
+    // walked the set bits of its rows' masks, a chain of dependent LDS reads: 16 k of the kernel's 36 k cycles per DAG.)
+    f4 aW1[6], alab[2];
 #pragma unroll
-    for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) aW1[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) alab[k] = 0.f;
+    for (int k = 0; k < 6; ++k) aW1[k] = f4_zero();
+    alab[0] = alab[1] = f4_zero();
     f4 dW2[4][2], dlabb[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dW2[i][0] = dW2[i][1] = f4_zero();
     dlabb[0] = dlabb[1] = f4_zero();
-    const int fW = threadIdx.x & 63;              // this thread's W1 column; rows (threadIdx.x >> 6) + 4k
-    const int fL = threadIdx.x & 31;              // label table: feature fL, classes (threadIdx.x >> 5) + 8k
+    unsigned long long wst_ = 0;
+#ifdef DVS_STAMPS
+    wst_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
@@ -698,10 +732,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd_w(EmbedArgs a, const float* g
             if (L.wave == 0 && L.lane < DVS_WTOK) parents[L.lane] = mypar;
             for (int p = L.wave; p < DVS_WTOK; p += 4) {
                 const uint64_t pm = __ballot(mypos == p), lm = __ballot(mylab == p);
-                const uint64_t qm = __ballot((mypar & pm) != 0ull);
                 if (L.lane == 0) {
                     posmask[p] = pm;
-                    parmask[p] = qm;
                     labmask[p] = lm;
                 }
             }
@@ -756,40 +788,68 @@ __global__ __launch_bounds__(256) void k_embed_bwd_w(EmbedArgs a, const float* g
 #pragma unroll
             for (int t = 0; t < 2; ++t) *(f4*)(DLE + (tok0 + L.r) * EMBW_DLE_LD + 16 * t + 4 * L.g) = dles[t];
         }
+        WCSTAMP(0);
         __syncthreads();
-        // ---- owner-computes scatters ---------------------------------------------------------------------------------
+        WCSTAMP(1);
+        // ---- scatters as selector-matrix products --------------------------------------------------------------------
+        {
+            uint64_t mp[6];              // this lane's row p = 16 pt + r of d W1: the tokens at its position (0: row beyond 2 N)
+            bool par_row[6];
 #pragma unroll
-        for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) {
-            const int prow = (threadIdx.x >> 6) + 4 * k;
-            if (prow < N) {
-                for (uint64_t m = posmask[prow]; m; m &= m - 1) aW1[k] += DE1[dvs_ctz64(m) * DVS_LD + fW];
-            } else if (prow < 2 * N) {
-                const uint64_t pm = posmask[prow - N];
-                for (uint64_t m = parmask[prow - N]; m; m &= m - 1) {
-                    const int i = dvs_ctz64(m);
-                    aW1[k] += (float)__popcll(parents[i] & pm) * DE1[i * DVS_LD + fW];
+            for (int pt = 0; pt < 6; ++pt) {
+                const int prow = 16 * pt + L.r;
+                par_row[pt] = prow >= N;
+                mp[pt] = prow < N ? posmask[prow] : (prow < 2 * N ? posmask[prow - N] : 0ull);
+            }
+            const int lt0 = L.wave, lt1 = L.wave + 4;                  // label tiles: class tile lt % 3, feature tile lt / 3
+            const uint64_t ml0 = labmask[16 * (lt0 % 3) + L.r], ml1 = lt1 < 6 ? labmask[16 * (lt1 % 3) + L.r] : 0ull;
+            const int npt = (2 * N + 15) >> 4;
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int i = 16 * kt + 4 * kk + L.g;             // token of this contraction step
+                    const float b = DE1[i * DVS_LD + 16 * L.wave + L.r];
+                    const uint64_t bit = 1ull << i, pari = parents[i];
+#pragma unroll
+                    for (int pt = 0; pt < 6; ++pt) {
+                        if (pt < npt) {
+                            const uint64_t x = mp[pt] & (par_row[pt] ? pari : bit);
+                            aW1[pt] = dvs_mfma((float)__popcll(x), b, aW1[pt]);
+                        }
+                    }
+                    const float bl0 = DLE[i * EMBW_DLE_LD + 16 * (lt0 / 3) + L.r];
+                    alab[0] = dvs_mfma((ml0 & bit) ? 1.f : 0.f, bl0, alab[0]);
+                    if (lt1 < 6) {
+                        const float bl1 = DLE[i * EMBW_DLE_LD + 16 * (lt1 / 3) + L.r];
+                        alab[1] = dvs_mfma((ml1 & bit) ? 1.f : 0.f, bl1, alab[1]);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) {
-            const int c = (threadIdx.x >> 5) + 8 * k;
-            if (c < C)
-                for (uint64_t m = labmask[c]; m; m &= m - 1) alab[k] += DLE[dvs_ctz64(m) * EMBW_DLE_LD + fL];
-        }
+        WCSTAMP(2);
         __syncthreads();
+        WCSTAMP(3);
     }
     __syncthreads();
     float* slab = a.slab + (size_t)blockIdx.x * a.P;
+    // D layout: register reg of lane (r, g) is element [row 4g + reg][column r] of the tile
 #pragma unroll
-    for (int k = 0; k < EMBW_W1_PER_THREAD; ++k) {
-        const int prow = (threadIdx.x >> 6) + 4 * k;
-        if (prow < 2 * N) slab[a.oW1 + (size_t)prow * 64 + fW] = aW1[k];
-    }
+    for (int pt = 0; pt < 6; ++pt)
 #pragma unroll
-    for (int k = 0; k < EMBW_LAB_PER_THREAD; ++k) {
-        const int c = (threadIdx.x >> 5) + 8 * k;
-        if (c < C) slab[a.olab_w + (size_t)fL * C + c] = alab[k];
+        for (int reg = 0; reg < 4; ++reg) {
+            const int prow = 16 * pt + 4 * L.g + reg;
+            if (prow < 2 * N) slab[a.oW1 + (size_t)prow * 64 + 16 * L.wave + L.r] = aW1[pt][reg];
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int lt = L.wave + 4 * k;
+        if (lt < 6) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int c = 16 * (lt % 3) + 4 * L.g + reg, f = 16 * (lt / 3) + L.r;
+                if (c < C) slab[a.olab_w + (size_t)f * C + c] = alab[k][reg];
+            }
+        }
     }
     float* rW2 = (float*)smem;                 // 4 * 2048
     float* rv = rW2 + 4 * 2048;                // 4 * 32

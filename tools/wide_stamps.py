@@ -16,12 +16,16 @@ f = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in f.items()}
 for _ in range(2): train_batch(f, model, opt)
 torch.cuda.synchronize()
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-fn = lib.dvs_debug_read_stamps_wb if which == "bwd" else lib.dvs_debug_read_stamps_w; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+fn = {"bwd": lib.dvs_debug_read_stamps_wb, "heads": lib.dvs_debug_read_stamps_wc}.get(which, lib.dvs_debug_read_stamps_w); fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 buf = np.zeros(256*8*8, np.uint64); fn(buf.ctypes.data, buf.nbytes, 1)
 train_batch(f, model, opt); torch.cuda.synchronize()
 fn(buf.ctypes.data, buf.nbytes, 0)
 t = buf.reshape(256, 8, 8).astype(np.float64) / (9 * 8)     # 9 launches x 8 DAGs per workgroup
-if which == "bwd":
+if which == "heads":
+    t = buf.reshape(256, 8, 8).astype(np.float64) / 8      # one launch each, 8 DAGs per workgroup
+    print("cycles per DAG (mean over WGs): k_embed_bwd_w 0 tile stage 1 barrier 2 scatters 3 barrier | k_loss_bwd_w 4 heads, U, V 5 barrier + pass 1 6 barrier + pass 2 7 barrier + edge matrices, d h, store + barrier")
+    for w in range(4): print("wave", w, np.round(t[:, w, :8].mean(0)).astype(int).tolist(), "sums", int(t[:, w, 0:4].mean(0).sum()), int(t[:, w, 4:8].mean(0).sum()))
+elif which == "bwd":
     print("k_attn_bwd_w, cycles per DAG (mean over WGs): 0 prologue(per launch/72) 1 fill: loads issued 2 fill: dO tile 3 core 4 (core end) 5 barrier 6 stores + parks | fill: q / k / v parked 7 barrier + dWo + barrier")
     for w in range(8): print("wave", w, np.round(t[:, w, :8].mean(0)).astype(int).tolist(), "sum", int(t[:, w, 1:8].mean(0).sum()))
 else:

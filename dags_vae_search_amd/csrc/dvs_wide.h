@@ -184,11 +184,11 @@ __device__ __forceinline__ LossWLds lossw_lds(char* smem) {
     l.pV = l.pU + 4 * DVS_SCR;                  // likewise dV
     return l;
 }
-// forward: the images, V and 16 floats of per-wave partial sums (in the first words of what is U in the backward) — 65 KB, two
-// workgroups per CU (the kernel runs 3 of its 4 waves at N = 40, one per SIMD: it is latency-bound)
+// forward: the images, V, U and 16 floats of per-wave partial sums (in the first words of what is the d logit matrix in the
+// backward) — 78 KB, two workgroups per CU (one wave per SIMD: the kernel is latency-bound)
 static inline size_t dvs_lossw_lds_floats(bool backward = true) {
     const size_t head = 32 * DVS_LD + DVS_WTOK * LOSSW_LDN2 + 128 * DVS_LD + 32 + DVS_WTOK + 64 + 64 + 16 + 128;
-    if (!backward) return head + (size_t)DVS_WSCR + 16;
+    if (!backward) return head + 2 * (size_t)DVS_WSCR + 16;
     return head + 2 * (size_t)DVS_WSCR + DVS_WTOK * (DVS_WTOK + 1) + 16 + 12 * (size_t)DVS_SCR;
 }
 __device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a, bool backward = true) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void lossw_stage(const LossWLds& l, const LossArgs& a
     if (threadIdx.x == 0) l.b2[0] = a.edge2_b[0];
     dvs_stage_vector(l.lg, a.ln.g, 64);
     dvs_stage_vector(l.lb, a.ln.b, 64);
-    for (int i = threadIdx.x; i < (backward ? 2 : 1) * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * DVS_WSCR; i += blockDim.x) l.V[i] = 0.f;
 }
 // backward only: the per-wave transpose tiles and the parked dU / dV blocks start as zeros (blocks of tiles the DAG does not
 // have — tile 3 always — are never written and are contracted as they are)

@@ -468,9 +468,12 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
     for (int dag = blockIdx.x; dag < a.dims.B; dag += gridDim.x) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
-        f4 h[4], xhat[4], hN[4], dh[4], U[4], V[4], w2v[4], dU[4], dV[4];
+        f4 h[4], xhat[4], dh[4], w2v[4], dU[4], dV[4];
         float rstd = 1.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w2v[t] = dvs_vecT(l.w2, t, L);      // (every wave: all four share the pair walks)
         if (has_tile) {
+            f4 hN[4], U[4], V[4];
             dvs_load_x<true>(h, xhat, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
             dvs_t2n<4>(hN, h, scr, L);
 #pragma unroll
@@ -540,7 +543,6 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
             for (int t = 0; t < 4; ++t) {
                 U[t] = f4_zero();
                 V[t] = dvs_vecT(l.be1, t, L);
-                w2v[t] = dvs_vecT(l.w2, t, L);
                 dU[t] = dV[t] = f4_zero();
             }
             dvs_mat_T<4, 4>(U, h, l.Wa, DVS_LD, 0, L);
@@ -550,67 +552,150 @@ __global__ __launch_bounds__(256) void k_loss_bwd_w(LossArgs a) {
         }
         WCSTAMP(4);
         __syncthreads();
-        if (has_tile) {
-            // pass 1: lane r = token i walks j < i; accumulates dU, dw2, db2; publishes d logit(i, j)
-            const uint64_t par = rec->parents[tok + 1 < DVS_WTOK ? tok + 1 : 0];
-            const int jend = (N - 2 < tok0 + 15) ? N - 2 : tok0 + 15;
-            // written for instruction count, as k_loss_bwd's passes: f4 arithmetic, w2 factored out (dU = w2 * sU), the ReLU
-            // derivative as a clamped multiply
-            f4 sU[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-            for (int j = 0; j < jend; ++j) {
-                f4 pre[4], ev = f4_zero();
+        // ---- the two pair walks, shared evenly by the FOUR waves --------------------------------------------------------------
+        // A walk step is (token tile t, partner index): pass 1 — lane r = token i = 16 t + r walks j < i: d logit(i, j), dU_i, dw2,
+        // db2 —, pass 2 — lane r = token j walks i > j: dV_j.  Tile t has min(N - 2, 16 t + 15) steps in pass 1 and
+        // N - 1 - max(16 t + 1, 1) in pass 2: with one tile per wave the walks lasted as long as their longest tile (38 of 84 and
+        // 38 of 66 steps at N = 40, the wave without a tile idle: 24 k + 21 k of the kernel's 69 k cycles per DAG,
+        // `profiles/r03_wide_stamps_heads.txt`).  Now the steps of all tiles, in tile order, are cut into four equal ranges; a wave
+        // takes U_t (pass 2: V_t) of the tiles its range touches from LDS, and its partial sums go to the tile's owner through a
+        // slot (the per-wave transpose tiles and the parked dU / dV blocks are free during the walks), added in wave order.
+        const int slots_per_wave = NT == 1 ? 1 : 2;
+        auto slot_of = [&](int id) -> float* {
+            return id < 4 ? l.scr + id * DVS_SCR : (id < 4 + NT ? l.pU + (id - 4) * DVS_SCR : l.pV + (id - 4 - NT) * DVS_SCR);
+        };
+        // steps of tile t in a pass and the first partner index
+        auto steps1 = [&](int t) { const int e = N - 2 < 16 * t + 15 ? N - 2 : 16 * t + 15; return t < NT && e > 0 ? e : 0; };
+        auto first2 = [&](int t) { return 16 * t + 1 > 1 ? 16 * t + 1 : 1; };
+        auto steps2 = [&](int t) { const int c = N - 1 - first2(t); return t < NT && c > 0 ? c : 0; };
+        // this wave's share [lo, hi) of tile t's steps when `total` steps in tile order are cut into 4 ranges of q
+        auto share = [&](int w, int q, int off, int cnt, int& lo, int& hi) {
+            const int g0 = w * q, g1 = g0 + q;
+            lo = (g0 > off ? g0 : off) - off;
+            hi = (g1 < off + cnt ? g1 : off + cnt) - off;
+        };
+        // owner side: sum of the partial tiles of tile `t`, in wave order
+        auto gather = [&](int t, int q, bool pass2, f4 (&sum)[4]) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f4 x = U[t] + *(const f4*)(l.V + j * DVS_LD + 16 * t + 4 * L.g);
+            for (int tt = 0; tt < 4; ++tt) sum[tt] = f4_zero();
+            for (int w = 0; w < 4; ++w) {
+                int off = 0, part = 0;
+                for (int u = 0; u < DVS_WNT; ++u) {
+                    const int cnt = pass2 ? steps2(u) : steps1(u);
+                    int lo, hi;
+                    share(w, q, off, cnt, lo, hi);
+                    if (lo < hi) {
+                        if (u == t) {
+                            const f4* sl = (const f4*)slot_of(w * slots_per_wave + part) + L.lane;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) pre[t][kk] = fmaxf(x[kk], 0.f);
-                    ev += w2v[t] * pre[t];
-                }
-                const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
-                const bool pv = (tok > j) && (tok <= N - 2);
-                const float truth = (float)((par >> (j + 1)) & 1ull);
-                const float sg = dvs_rcp(1.0f + __expf(-logit));
-                const float dl = pv ? gr * (sg - truth) : 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    dw2[t] += pre[t] * dl;
-                    f4 st;
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(pre[t][kk] * 1.0e30f, 0.f), 1.f);
-                    sU[t] += st * dl;
-                }
-                if (L.g == 0) {
-                    db2 += dl;
-                    l.dlm[tok * DLD + j] = dl;
+                            for (int tt = 0; tt < 4; ++tt) sum[tt] += sl[tt * 64];
+                        }
+                        ++part;
+                    }
+                    off += cnt;
                 }
             }
+        };
+        const int total1 = steps1(0) + steps1(1) + steps1(2), q1 = (total1 + 3) >> 2;
+        const int total2 = steps2(0) + steps2(1) + steps2(2), q2 = (total2 + 3) >> 2;
+        {
+            // pass 1
+            int off = 0, part = 0;
+            for (int t = 0; t < DVS_WNT; ++t) {
+                const int cnt = steps1(t);
+                int lo, hi;
+                share(L.wave, q1, off, cnt, lo, hi);
+                off += cnt;
+                if (lo >= hi) continue;
+                const int ptok = 16 * t + L.r;
+                f4 Ut[4];
+                dvs_lds_T(Ut, l.U, 16 * t, L);
+                const uint64_t par = rec->parents[ptok + 1 < DVS_WTOK ? ptok + 1 : 0];
+                // written for instruction count, as k_loss_bwd's passes: f4 arithmetic, w2 factored out (dU = w2 * sU), the ReLU
+                // derivative as a clamped multiply
+                f4 sU[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+                for (int j = lo; j < hi; ++j) {
+                    f4 pre[4], ev = f4_zero();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dU[t] = w2v[t] * sU[t];
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f4 x = Ut[tt] + *(const f4*)(l.V + j * DVS_LD + 16 * tt + 4 * L.g);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pre[tt][kk] = fmaxf(x[kk], 0.f);
+                        ev += w2v[tt] * pre[tt];
+                    }
+                    const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
+                    const bool pv = (ptok > j) && (ptok <= N - 2);
+                    const float truth = (float)((par >> (j + 1)) & 1ull);
+                    const float sg = dvs_rcp(1.0f + __expf(-logit));
+                    const float dl = pv ? gr * (sg - truth) : 0.f;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        dw2[tt] += pre[tt] * dl;
+                        f4 st;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(pre[tt][kk] * 1.0e30f, 0.f), 1.f);
+                        sU[tt] += st * dl;
+                    }
+                    if (L.g == 0) {
+                        db2 += dl;
+                        l.dlm[ptok * DLD + j] = dl;
+                    }
+                }
+                f4* sl = (f4*)slot_of(L.wave * slots_per_wave + part) + L.lane;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) sl[tt * 64] = sU[tt];
+                ++part;
+            }
         }
         WCSTAMP(5);
         __syncthreads();
         if (has_tile) {
-            // pass 2: lane r = token j walks i > j; accumulates dV
-            const int i0 = tok0 + 1 > 1 ? tok0 + 1 : 1;
-            f4 sV[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-            for (int i = i0; i <= N - 2; ++i) {
-                const float dl = (tok < i) ? l.dlm[i * DLD + tok] : 0.f;
+            gather(L.wave, q1, false, dU);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f4 x = *(const f4*)(l.U + i * DVS_LD + 16 * t + 4 * L.g) + V[t];
-                    f4 st;
+            for (int t = 0; t < 4; ++t) dU[t] = w2v[t] * dU[t];
+        }
+        __syncthreads();                 // the slots are free again
+        {
+            // pass 2
+            int off = 0, part = 0;
+            for (int t = 0; t < DVS_WNT; ++t) {
+                const int cnt = steps2(t);
+                int lo, hi;
+                share(L.wave, q2, off, cnt, lo, hi);
+                off += cnt;
+                if (lo >= hi) continue;
+                const int ptok = 16 * t + L.r, i0 = first2(t);
+                f4 Vt[4];
+                dvs_lds_T(Vt, l.V, 16 * t, L);
+                f4 sV[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
+                for (int i = i0 + lo; i < i0 + hi; ++i) {
+                    const float dl = (ptok < i) ? l.dlm[i * DLD + ptok] : 0.f;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(x[kk] * 1.0e30f, 0.f), 1.f);
-                    sV[t] += st * dl;
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f4 x = *(const f4*)(l.U + i * DVS_LD + 16 * tt + 4 * L.g) + Vt[tt];
+                        f4 st;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) st[kk] = fminf(fmaxf(x[kk] * 1.0e30f, 0.f), 1.f);
+                        sV[tt] += st * dl;
+                    }
                 }
-            }
+                f4* sl = (f4*)slot_of(L.wave * slots_per_wave + part) + L.lane;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dV[t] = w2v[t] * sV[t];
+                for (int tt = 0; tt < 4; ++tt) sl[tt * 64] = sV[tt];
+                ++part;
+            }
+        }
+        WCSTAMP(6);
+        __syncthreads();
+        if (has_tile) gather(L.wave, q2, true, dV);
+        __syncthreads();                 // every owner has its sums: the slots become the parked tiles
+        if (has_tile) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dV[t] = w2v[t] * dV[t];
             dvs_park_bf(pU + L.wave * 2 * DVS_SCR, dU, L);
             dvs_park_bf(pV + L.wave * 2 * DVS_SCR, dV, L);
             dvs_park_bf((dvs_bf16*)scr, h, L);                        // the wave's transpose tile is free by now
         }
-        WCSTAMP(6);
         __syncthreads();
         dvsw_coop_dw(aWa, abU, pU, (const dvs_bf16*)l.scr, NT, L);   // all four waves (wave 3 has no tile but owns rows 48..63)
         dvsw_coop_dw(aWb, abV, pV, (const dvs_bf16*)l.scr, NT, L);

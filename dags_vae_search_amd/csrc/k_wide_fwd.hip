@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
     DVS_DYN_LDS(smem);
     const LossWLds l = lossw_lds(smem);
     lossw_stage(l, a, false);
-    float* const part = l.U;                              // (forward layout: dvs_lossw_lds_floats(false))
+    float* const part = l.dlm;                            // (forward layout: dvs_lossw_lds_floats(false))
     __syncthreads();
     const Lane L = dvs_lane();
     const int N = a.dims.N, C = a.dims.C, NT = a.dims.NT;
@@ -589,9 +589,12 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + dag;
         const size_t tile = (size_t)dag * NT + L.wave;
         float nll = 0.f;
-        f4 U[4], w2v[4];
+        f4 w2v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w2v[t] = dvs_vecT(l.w2, t, L);
         const int tok = tok0 + L.r;                       // this lane's token
         if (has_tile) {
+            f4 U[4];
             f4 h[4], dummy[4];
             float rstd;
             dvs_load_x<false>(h, dummy, rstd, a.xin, a.ln, l.lg, l.lb, tile, Nl, L);
@@ -633,33 +636,49 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
             for (int t = 0; t < 4; ++t) {
                 U[t] = f4_zero();
                 V[t] = dvs_vecT(l.be1, t, L);
-                w2v[t] = dvs_vecT(l.w2, t, L);
             }
             dvs_mat_T<4, 4>(U, h, l.Wa, DVS_LD, 0, L);
             dvs_mat_T<4, 4>(V, h, l.Wb, DVS_LD, 0, L);
             dvs_park_T(l.V + tok0 * DVS_LD, V, L);
+            dvs_park_T(l.U + tok0 * DVS_LD, U, L);
         }
         __syncthreads();
-        if (has_tile) {
-            const uint64_t par = rec->parents[tok + 1 < DVS_WTOK ? tok + 1 : 0];
+        // The pair walk — lane r = token i = 16 t + r walks j < i —, shared evenly by the FOUR waves (k_loss_bwd_w's pass 1): tile t
+        // has min(N - 2, 16 t + 15) steps; the steps of all tiles, in tile order, are cut into four equal ranges, and a wave takes
+        // U_t of the tiles its range touches from LDS.  (One tile per wave: the walk lasted as long as the last tile's, 38 of 84
+        // steps at N = 40, and the fourth wave idled.)
+        {
+            auto steps1 = [&](int t) { const int e = N - 2 < 16 * t + 15 ? N - 2 : 16 * t + 15; return t < NT && e > 0 ? e : 0; };
+            const int total = steps1(0) + steps1(1) + steps1(2), q = (total + 3) >> 2;
+            const int g0 = L.wave * q, g1 = g0 + q;
             float enll = 0.f;
-            const int jend = (N - 2 < tok0 + 15) ? N - 2 : tok0 + 15;     // pairs need j < i <= tok0 + 15
-            for (int j = 0; j < jend; ++j) {
-                f4 ev = f4_zero();
+            int off = 0;
+            for (int t = 0; t < DVS_WNT; ++t) {
+                const int cnt = steps1(t);
+                const int lo = (g0 > off ? g0 : off) - off, hi = (g1 < off + cnt ? g1 : off + cnt) - off;
+                off += cnt;
+                if (lo >= hi) continue;
+                const int ptok = 16 * t + L.r;
+                f4 Ut[4];
+                dvs_lds_T(Ut, l.U, 16 * t, L);
+                const uint64_t par = rec->parents[ptok + 1 < DVS_WTOK ? ptok + 1 : 0];
+                for (int j = lo; j < hi; ++j) {
+                    f4 ev = f4_zero();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f4 x = U[t] + *(const f4*)(l.V + j * DVS_LD + 16 * t + 4 * L.g);
-                    f4 pre;
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f4 x = Ut[tt] + *(const f4*)(l.V + j * DVS_LD + 16 * tt + 4 * L.g);
+                        f4 pre;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) pre[kk] = fmaxf(x[kk], 0.f);
-                    ev += w2v[t] * pre;
+                        for (int kk = 0; kk < 4; ++kk) pre[kk] = fmaxf(x[kk], 0.f);
+                        ev += w2v[tt] * pre;
+                    }
+                    const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
+                    const bool pv = (ptok > j) && (ptok <= N - 2);
+                    const float truth = (float)((par >> (j + 1)) & 1ull);
+                    // hardware exp / log (k_loss_fwd): log1p's range handling costs ~40 instructions for <= 1e-7 of a term in (0, ln 2]
+                    const float bce = fmaxf(logit, 0.f) - logit * truth + __logf(1.0f + __expf(-fabsf(logit)));
+                    enll += pv ? bce : 0.f;
                 }
-                const float logit = dvs_sum_g((ev[0] + ev[1]) + (ev[2] + ev[3])) + b2;
-                const bool pv = (tok > j) && (tok <= N - 2);
-                const float truth = (float)((par >> (j + 1)) & 1ull);
-                // hardware exp / log (k_loss_fwd): log1p's range handling costs ~40 instructions for <= 1e-7 of a term in (0, ln 2]
-                const float bce = fmaxf(logit, 0.f) - logit * truth + __logf(1.0f + __expf(-fabsf(logit)));
-                enll += pv ? bce : 0.f;
             }
             nll += (L.g == 0) ? enll : 0.f;
             nll = dvs_sum_wave(nll);
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd_w(LossArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             float s = 0.f;
-            for (int w = 0; w < NT; ++w) s += part[w];
+            for (int w = 0; w < 4; ++w) s += part[w];
             a.dag_loss[(size_t)dag * 2] = s;
         }
     }

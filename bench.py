@@ -68,6 +68,9 @@ def algo_flops_per_dag(N: int, C: int):
     a = dict(f)
     a.update({"k_loss_bwd": 2 * (node + edge), "k_ffn_bwd": 2 * 2 * proj, "k_attn_bwd": 2 * (proj + core)})
 
+    # the wide attention backward reads q, k, v back from the forward (round 3): it recomputes the probabilities only
+    f["k_attn_bwd_w"] = core + 2 * (proj + core)
+    a["k_attn_bwd_w"] = a["k_attn_bwd"]
     # chained launches (one-tile path): the sum over the sublayers one launch walks.  The decoder's 18 backward phases
     # go out as two launches of 9, so its per-launch figure is half the decoder total.
     for t in (f, a):
@@ -329,7 +332,7 @@ def main():
         kern = {k: {"launches_per_step": c // prof_steps, "avg_us": 1e3 * ms / c, "ms_per_step": ms / prof_steps}
                 for k, (c, ms) in prof.items()}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        dom_key = dom[:-2] if dom.endswith("_w") else dom          # wide-path kernels: same algorithmic work
+        dom_key = dom if dom in executed else (dom[:-2] if dom.endswith("_w") else dom)      # wide-path kernels: same algorithmic work
         per_launch_s = kern[dom]["avg_us"] * 1e-6
         ach = algo.get(dom_key, 0.0) * local_batch / per_launch_s / 1e12
         hfu = executed.get(dom_key, 0.0) * local_batch / per_launch_s / 1e12

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_w(AttnArgs a) {
         }
         // the projection waves touch their input tile(s) of the workgroup's NEXT DAG ahead of the core (one 4-byte load per lane:
         // every line of the tile; consumed behind the core): stage 1 opened with a cold load (4-7 k cycles on this machine).
-        // Measured: k_attn_fwd_w 78.2 -> 76.6 us.  (Tried and dropped, `gpurun_out/r03_ab_alarm1{6,8}.txt`: k / v of the next DAG
+        // Measured: k_attn_fwd_w 78.2 -> 76.6 us.  (Tried and dropped, `profiles/r03_ab_alarm1{6,8}.txt`: k / v of the next DAG
         // projected by the waves stage 3 leaves idle (+5 %: five waves need 7.9 k cycles for them, stage 3 lasts 3.6 k), stage 1
         // spread over all eight waves (no change: the stage is not bound by the output tiles per wave).)
         float tch0 = 0.f, tch1 = 0.f;

@@ -80,6 +80,8 @@ static size_t ffnb_lds_bytes() {
     return 7 * 64 * DVS_LDB * sizeof(dvs_bf16) + (6 * 64 + (size_t)8 * 2 * DVS_SCR + 16) * sizeof(float);
 }
 
+constexpr int DVS_ATTNB_TLD = 20;             // floats per row of the per-wave transposing tile (16 + 4: 16-byte rows, 2-way banks at most)
+constexpr int DVS_ATTNB_TSCR = 16 * DVS_ATTNB_TLD;
 struct AttnBLds {
     float *inb, *outb, *lg, *lb, *slots, *stats;
     // bf16x3 images (dvs_bf16.h): the in-projection rows (q, k, v are recomputed through a softmax — smooth, so their
@@ -100,11 +102,11 @@ DVS_HD inline AttnBLds attnb_lds(char* smem) {
     l.lb = l.lg + 64;
     l.gcount = (int*)(l.lb + 64);
     l.slots = (float*)(l.gcount + 4);          // per wave: A (d y, row-major) and B (transpose scratch, then O)
-    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave 128 floats: lse / delta exchange
+    l.stats = l.slots + 8 * 2 * DVS_SCR;       // per wave DVS_ATTNB_TSCR floats: transposing tile of the core
     return l;
 }
 static size_t attnb_lds_floats() {
-    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * 128 + 16;
+    return 512 * DVS_LDB / 2 + 192 + 64 + 128 + (size_t)8 * 2 * DVS_SCR + 8 * DVS_ATTNB_TSCR + 16;
 }
 
 
@@ -623,7 +625,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
     const int N = a.dims.N, B = a.dims.B;
     float* sA = l.slots + L.wave * 2 * DVS_SCR;
     float* sB = sA + DVS_SCR;
-    float* st = l.stats + L.wave * 128;
+    float* st = l.stats + L.wave * DVS_ATTNB_TSCR;
     DvsGroup G = {l.gcount + (L.wave >> 2), 0};
     const float scale = 0.35355339059327373f;
     f4 aWo[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
@@ -703,8 +705,8 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // ---- T orientation: reg <-> (query i = r, key j = 4g+reg) --------------------------------------------
-            f4 pT[2], dsT[2];
-            float lse[2], delta[2];
+            f4 pT[2], dsT[2], ds[2], pd[2];
+            float delta[2];
             {
                 f4 sT[2] = {f4_zero(), f4_zero()};
 #pragma unroll
@@ -739,10 +741,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
 #pragma unroll
                 for (int u = 0; u < 2; ++u) den[u] = dvs_add_x32(den[u]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    pT[u] *= (1.0f / den[u]);
-                    lse[u] = m[u] + __logf(den[u]);
-                }
+                for (int u = 0; u < 2; ++u) pT[u] *= (1.0f / den[u]);
             }
             {
                 f4 mk[2], dpT[2];
@@ -790,6 +789,24 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) dsT[u][reg] = pT[u][reg] * (dpT[u][reg] - delta[u]);
+                // dk and dv contract over the QUERIES: they need dS and P' with lane r <-> key j, register <-> query 4g + reg.
+                // The four 16 x 16 tiles of the head pair go through the wave's transposing tile, one after the other (the LDS
+                // queue of a wave is in order: the next tile's write is queued behind this one's reads; one wait for all four) —
+                // rounds 1-3 recomputed scores, exponentials and masks in that orientation (8 MFMAs and ~100 vector
+                // instructions per pass, the row statistics exchanged through LDS)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    *(f4*)(st + L.r * DVS_ATTNB_TLD + 4 * L.g) = dsT[u];
+                    dvs_wave_sync();
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) ds[u][reg] = st[(4 * L.g + reg) * DVS_ATTNB_TLD + L.r];
+                    dvs_wave_sync();
+                    *(f4*)(st + L.r * DVS_ATTNB_TLD + 4 * L.g) = pT[u] * mk[u];
+                    dvs_wave_sync();
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pd[u][reg] = st[(4 * L.g + reg) * DVS_ATTNB_TLD + L.r];
+                    dvs_wave_sync();
+                }
             }
             // dq^T = K^T dS^T: all 16 slot rows per head, merged by register; stored at once (scaled by 1/sqrt(dh))
             {
@@ -802,40 +819,8 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
                 const f4 dq = f4{qa[0], qa[1], qb[2], qb[3]} * scale;
                 if (live) ((f4*)(a.gq + dg * DVS_TILE))[t * 64 + L.lane] = dq;
             }
-            // row statistics (lse, delta) move from lanes r = i to the S-orientation registers i = 4g+reg
-            if (L.g == 0) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    st[u * 32 + L.r] = lse[u];
-                    st[u * 32 + 16 + L.r] = delta[u];
-                }
-            }
-            dvs_wave_sync();
-            // ---- S orientation: reg <-> (query i = 4g+reg, key j = r) --------------------------------------------
+            // ---- S orientation (reg <-> query i = 4g+reg, lane r <-> key j): ds, pd from the transposes above ------------
             {
-                f4 s2[2] = {f4_zero(), f4_zero()}, dp[2] = {f4_zero(), f4_zero()};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    s2[0] = dvs_mfma(q[t][kk], k[t][kk], s2[0]);
-                    s2[1] = dvs_mfma(q[t][kk + 2], k[t][kk + 2], s2[1]);
-                    dp[0] = dvs_mfma(dOT[t][kk], vT[t][kk], dp[0]);
-                    dp[1] = dvs_mfma(dOT[t][kk + 2], vT[t][kk + 2], dp[1]);
-                }
-                f4 ds[2], pd[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f4 lse_i = *(const f4*)(st + u * 32 + 4 * L.g);
-                    const f4 del_i = *(const f4*)(st + u * 32 + 16 + 4 * L.g);
-                    const f4 mk = mask_S(pm, 2 * t + u, D);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const bool oki = (al4[reg] >> L.r) & 1u;
-                        const float p = oki ? __expf(s2[u][reg] - lse_i[reg]) : 0.f;
-                        ds[u][reg] = p * (dp[u][reg] * mk[reg] - del_i[reg]);
-                        pd[u][reg] = p * mk[reg];
-                    }
-                }
-                dvs_wave_sync();
                 // dk^T = Q^T dS ;  dv^T = dO^T P'  (per head on all slot rows, merged by register), stored at once
                 f4 ka = f4_zero(), kb = f4_zero(), va = f4_zero(), vb = f4_zero();
 #pragma unroll

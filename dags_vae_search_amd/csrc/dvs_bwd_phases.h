@@ -310,6 +310,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         }
         if (live) dvs_store_tile(a.gout, dag, dx, L);
         DVS_ROUND_TOUCH_DONE(rt);
+        if (base == dvs_bid() * NW) DVS_STAMP(dvs_stamps_bwd, mine, 7);      // end of the first round (tools/phase_stamps.py)
     }
     DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
@@ -490,6 +491,7 @@ __device__ __forceinline__ void dvs_proj_bwd_phase(const ProjBwdArgs& a, char* s
             }
         }
         DVS_ROUND_TOUCH_DONE(rt);
+        if (base == dvs_bid() * NW) DVS_STAMP(dvs_stamps_bwd, mine, 7);
     }
     DVS_PHASE_GATE(gate);                                  // a workgroup without a tile
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
@@ -841,6 +843,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
         dvs_group_barrier(G, L);
         dvs_coop_dw_bf(aWo, abo, (const dvs_bf16*)l.slots, (const dvs_bf16*)l.slots + 2 * DVS_SCR, 2 * 2 * DVS_SCR, L);
         dvs_group_barrier(G, L);
+        if (base == dvs_bid() * NW) DVS_STAMP(dvs_stamps_bwd, mine, 7);
     }
     DVS_STAMP(dvs_stamps_bwd, mine, 2);
     // every wave touches its first tiles of the next phase (dvs_stage.h) — BEHIND the older group's image prefetch: ahead of it

@@ -77,9 +77,14 @@ def main():
             base = e5 if e5[:, 0].any() else a4
             commit = m(c6[:, 0] - base[:, 0]) if c6[:, 0].any() else 0.0
             total = m(nxt[:, 0] - e0[:, 0]) if nxt is not None else 0.0
-            again = m(t[:, 0, ph, 7] - c6[:, 0]) if t[:, 0, ph, 7].any() else 0.0      # DVS_STAMPS_ICACHE builds only
-            print(f"{ph:5d} {stage:7.0f} {loop_o:9.0f} {loop_y:8.0f} {issue:7.0f} {wa_o:11.0f} {wa_y:9.0f} {epi:7.0f} {commit:7.0f} {total:7.0f}"
-                  + (f"   commit repeated: {again:6.0f}" if again else ""))
+            s7 = t[:, :, ph, 7]
+            extra = ""
+            if name == "backward" and s7[:, 0].any():       # id 7 = end of the FIRST DAG round (backward phases)
+                extra = (f"   round 1 old/yng {m(s7[:, 0] - l0[:, 0]):6.0f} /{m(s7[:, 4] - l0[:, 4]):6.0f}"
+                         f"   later rounds {m(l1[:, 0] - s7[:, 0]):6.0f} /{m(l1[:, 4] - s7[:, 4]):6.0f}")
+            elif s7[:, 0].any():                              # DVS_STAMPS_ICACHE builds only (forward)
+                extra = f"   commit repeated: {m(s7[:, 0] - c6[:, 0]):6.0f}"
+            print(f"{ph:5d} {stage:7.0f} {loop_o:9.0f} {loop_y:8.0f} {issue:7.0f} {wa_o:11.0f} {wa_y:9.0f} {epi:7.0f} {commit:7.0f} {total:7.0f}" + extra)
 
 
 if __name__ == "__main__":

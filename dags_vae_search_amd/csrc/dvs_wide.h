@@ -6,9 +6,12 @@
 // 4-wave workgroup owns tile w (its MFMA chains are those of the one-tile kernels), and the tiles of a DAG meet in LDS:
 //   * positional embedding: every token gathers the W1 rows of its parents' positions from an LDS image of W1
 //     (pace.py:214 adj^T @ pos_onehot) — the parent-hidden gather BASELINE config 5 stresses;
-//   * attention core: q, k, v of all tiles are parked row-major in LDS, one thread per (token, head) walks the token's
-//     ancestor bit-row (scores, softmax, dropout, P'V on the VALU: 8-wide heads are below MFMA tile size);
-//   * edge-pair head: V = Wb h + b1 of all tokens parked in LDS, lane (token i) walks j < i.
+//   * attention core (8-wave workgroups): q, k, v of all tiles parked row-major in LDS, wave h = head h on the fp32 matrix pipe
+//     over the non-empty (query tile, key tile) pairs of the DAG's mask; the backward reads q, k, v back from the forward,
+//     walks the query tiles once (dS / P' tiles transposed through a per-wave LDS scratch) and keeps two DAGs in flight per
+//     workgroup (k_wide_fwd.hip, k_wide_bwd.hip);
+//   * edge-pair head: U, V of all tokens parked in LDS, lane (token i) walks j < i; the walk steps of all tiles are shared
+//     evenly by the four waves.
 // Workgroups are persistent (grid = #CU) so that weight gradients keep the slab scheme of dvs_backward.h.
 #pragma once
 #include "dvs_backward.h"
@@ -43,63 +46,6 @@ __device__ __forceinline__ void dvs_lds_N(f4 (&x)[4], const float* buf, int tok0
         const float* p = buf + (tok0 + 4 * L.g) * DVS_LD + 16 * t + L.r;
         x[t] = f4{p[0], p[DVS_LD], p[2 * DVS_LD], p[3 * DVS_LD]};
     }
-}
-
-// 8-deep dot product as two packed multiply-adds and a 3-add tree (was a chain of 8 dependent FMAs: the lane walks of the wide
-// attention backward are latency- and issue-bound).  Phases A and B both go through this function: identical scores.
-__device__ __forceinline__ float dvs_dot8(const f4& a0, const f4& a1, const float* p) {
-    const f4 b0 = *(const f4*)p, b1 = *(const f4*)(p + 4);
-    const f4 m = a1 * b1 + a0 * b0;
-    return (m[0] + m[1]) + (m[2] + m[3]);
-}
-
-// ---- attention-core item layout ------------------------------------------------------------------------------------------
-// One lane walks the bit-row of one (token, head); a wave runs for its longest row and the rows of late tokens are the
-// long ones (up to N keys).  The core phases have 512 lanes for 8N <= 384 items, so the LAST nsplit = min(N, 64 - N)
-// tokens get a lane PAIR per (token, head): each lane of the pair walks every other set bit of the row (rowE / rowO,
-// prepared once per DAG), and the two partial online-softmax states are merged with one DPP exchange (lane ^ 1).
-struct DvsCoreItem {
-    int tok, head, half;         // half: -1 = whole row, 0 / 1 = even / odd set bits; tok < 0: idle lane
-};
-__device__ __forceinline__ DvsCoreItem dvs_core_item(int N) {
-    int nsplit = 64 - N;
-    nsplit = nsplit < 0 ? 0 : (nsplit > N ? N : nsplit);
-    const int single = 8 * (N - nsplit), t = threadIdx.x;
-    DvsCoreItem it;
-    if (t < single) {
-        it.tok = t >> 3;
-        it.head = t & 7;
-        it.half = -1;
-    } else {
-        const int u = t - single;
-        it.tok = (N - nsplit) + (u >> 4);
-        it.head = (u >> 1) & 7;
-        it.half = u & 1;
-        if (it.tok >= N) it.tok = -1;
-    }
-    return it;
-}
-// split a bit-row into its even- and odd-ordinal set bits
-__device__ __forceinline__ void dvs_split_row(uint64_t row, uint64_t& even, uint64_t& odd) {
-    even = 0;
-    odd = 0;
-    bool e = true;
-    for (uint64_t m = row; m; m &= m - 1) {
-        const uint64_t bit = m & (~m + 1);
-        if (e) even |= bit; else odd |= bit;
-        e = !e;
-    }
-}
-// value held by lane (lane ^ 1)
-__device__ __forceinline__ float dvs_pair_xchg(float v) {
-#ifdef DVS_EMU
-    return emu::exchange(v, emu::g_cur->lane ^ 1);
-#else
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-#endif
-}
-__device__ __forceinline__ f4 dvs_pair_xchg(const f4& v) {
-    return f4{dvs_pair_xchg(v[0]), dvs_pair_xchg(v[1]), dvs_pair_xchg(v[2]), dvs_pair_xchg(v[3])};
 }
 
 // ---- LDS images shared by the forward and backward kernels ---------------------------------------------------------

@@ -267,7 +267,8 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) hd[t][kk] = (live && L.r < N) ? fmaxf(hpre[t][kk], 0.f) : 0.f;
-        dvs_dropout_tile(hd, khid, D, L, T.tok0);
+        const uint32_t hid_bits = dvs_dropout_bits(khid, D, L, T.tok0);      // drawn once, applied to h and to d h
+        dvs_dropout_apply(hd, hid_bits, D);
         // dy = d(W2 h + b2) = dropout-mask(post) applied to d pre
         f4 dy[4];
 #pragma unroll
@@ -280,7 +281,7 @@ __device__ __forceinline__ void dvs_ffn_bwd_phase(const FfnBwdArgs& a, char* sme
         dvs_coop_dw_bf(aW2, ab2, bslots, bslots + 2 * DVS_SCR, BSTRIDE, L);
         f4 dh[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
         dvs_matb_T<4>(dh, dvs_split_T(dy), l.W2Th, l.W2Tl, 0, L);
-        dvs_dropout_tile(dh, khid, D, L, T.tok0);
+        dvs_dropout_apply(dh, hid_bits, D);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -743,7 +744,7 @@ __device__ __forceinline__ void dvs_attn_bwd_phase(const AttnBwdArgs& a, char* s
 #pragma unroll
                 for (int u = 0; u < 2; ++u) den[u] = dvs_add_x32(den[u]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) pT[u] *= (1.0f / den[u]);
+                for (int u = 0; u < 2; ++u) pT[u] *= dvs_rcp(den[u]);      // (1 ulp: a gradient term, dvs_device.h)
             }
             {
                 f4 mk[2], dpT[2];

@@ -410,6 +410,33 @@ __device__ __forceinline__ void dvs_dropout_tile(f4 (&x)[NTILE], uint32_t key, c
         x[t][3] = ((h1 >> 16) >= D.thr16) ? x[t][3] * D.scale : 0.f;
     }
 }
+// the same draws as keep-bits (bit 4t + kk <-> x[t][kk]) and their application: a mask that is applied twice (the FFN backward's
+// hidden: to the recomputed activation and to its gradient) is drawn once
+template <int NTILE = 4>
+__device__ __forceinline__ uint32_t dvs_dropout_bits(uint32_t key, const DvsDrop& D, const Lane& L, int tok0 = 0) {
+    uint32_t bits = 0xFFFFFFFFu;
+    if (D.on) {
+        bits = 0;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const uint32_t p0 = (uint32_t)((tok0 + L.r) * 64 + 16 * t + 4 * L.g) >> 1;
+            const uint32_t h0 = dvs_draw(key, p0), h1 = dvs_draw(key, p0 + 1);
+            bits |= ((h0 & 0xFFFFu) >= D.thr16 ? 1u : 0u) << (4 * t);
+            bits |= ((h0 >> 16) >= D.thr16 ? 1u : 0u) << (4 * t + 1);
+            bits |= ((h1 & 0xFFFFu) >= D.thr16 ? 1u : 0u) << (4 * t + 2);
+            bits |= ((h1 >> 16) >= D.thr16 ? 1u : 0u) << (4 * t + 3);
+        }
+    }
+    return bits;
+}
+template <int NTILE = 4>
+__device__ __forceinline__ void dvs_dropout_apply(f4 (&x)[NTILE], uint32_t bits, const DvsDrop& D) {
+    if (!D.on) return;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x[t][kk] = ((bits >> (4 * t + kk)) & 1u) ? x[t][kk] * D.scale : 0.f;
+}
 // single element (used for attention probabilities): element index e
 __device__ __forceinline__ float dvs_dropout_elem(float v, uint32_t key, uint32_t e, const DvsDrop& D) {
     const uint32_t h = dvs_draw(key, e >> 1);

@@ -824,7 +824,7 @@ extern "C" int dvs_loss_forward_notify(const dvs_shape* s, const void* records, 
     const FwdGrids grid = fwd_grids(d, is_wide(s));
 
     prepare_images(L, d.N, d.C, grid.wide, params, ws, W, st);
-    const bool fused_dec_embed = d.drop.on && !grid.wide;
+    const bool fused_dec_embed = d.drop.on;
     encoder_forward(d, L, W, rec, params, ws, grid, st, latent_args(d, L, W, params, ws, eps, true), fused_dec_embed, true);
 
     // decoder input embedding: identical to the encoder's in eval mode / dropout 0 (pace.py:2000-2012 recomputes it

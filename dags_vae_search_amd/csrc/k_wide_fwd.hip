@@ -216,28 +216,11 @@ __global__ __launch_bounds__(256) void k_embed_fwd_w(EmbedArgs a) {
         const DvsTile T = dvs_tile_of(tile, a.dims);
         const DvsRecordW* rec = (const DvsRecordW*)a.rec + T.dag;
         const bool valid = L.r < T.Nl;
-        f4 e1[4];
-        embw_hidden(e1, l.W1, rec, l.posl + 16 * L.wave, N, T.tok0, T.Nl, L);
+        f4 e1h[4];
+        embw_hidden(e1h, l.W1, rec, l.posl + 16 * L.wave, N, T.tok0, T.Nl, L);
         const uint32_t gdag = a.dims.dag_offset + T.dag;
-        dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site, gdag), D, L, T.tok0);
-        f4 x[4];
-        f4 e2[2] = {f4_zero(), f4_zero()};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f4 w0 = dvs_wcol(l.W2, EMB_LDW2, 0, t, L), w1 = dvs_wcol(l.W2, EMB_LDW2, 16, t, L);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                e2[0] = dvs_mfma(w0[kk], e1[t][kk], e2[0]);
-                e2[1] = dvs_mfma(w1[kk], e1[t][kk], e2[1]);
-            }
-        }
-        {
-            f4 tmp[2] = {e2[0], e2[1]};
-            dvs_dropout_tile<2>(tmp, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, a.site + 1, gdag), D, L, T.tok0);
-            x[2] = tmp[0];
-            x[3] = tmp[1];
-        }
         const int label = rec->label[valid ? T.tok0 + L.r : 0];
+        f4 x[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -245,8 +228,29 @@ __global__ __launch_bounds__(256) void k_embed_fwd_w(EmbedArgs a) {
                 const int f = 16 * t + 4 * L.g + kk;
                 x[t][kk] = valid ? fmaxf(l.labw[f * EMBW_LABLD + label] + l.labb[f], 0.f) : 0.f;
             }
-        if (!valid) { x[2] = f4_zero(); x[3] = f4_zero(); }
-        dvs_store_tile(a.out, tile, x, L);
+        // the encoder-side embedding and, when asked for (out2: the decoder-side one, other dropout sites), a second one from the
+        // same parent walk (as the one-tile kernel does; it was a second launch)
+        for (int rep = 0; rep < (a.out2 ? 2 : 1); ++rep) {
+            const int site = rep == 0 ? a.site : a.site2;
+            f4 e1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) e1[t] = e1h[t];
+            dvs_dropout_tile(e1, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site, gdag), D, L, T.tok0);
+            f4 e2[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f4 w0 = dvs_wcol(l.W2, EMB_LDW2, 0, t, L), w1 = dvs_wcol(l.W2, EMB_LDW2, 16, t, L);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    e2[0] = dvs_mfma(w0[kk], e1[t][kk], e2[0]);
+                    e2[1] = dvs_mfma(w1[kk], e1[t][kk], e2[1]);
+                }
+            }
+            dvs_dropout_tile<2>(e2, dvs_site_key(a.dims.seed_lo, a.dims.seed_hi, site + 1, gdag), D, L, T.tok0);
+            x[2] = valid ? e2[0] : f4_zero();
+            x[3] = valid ? e2[1] : f4_zero();
+            dvs_store_tile(rep == 0 ? a.out : a.out2, tile, x, L);
+        }
     }
 }
 

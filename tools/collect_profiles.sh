@@ -18,9 +18,11 @@ cd /tmp && cd $ROOT
 python3 bench.py $ARGS --steps 50 --warmup 10 > $OUT/${TAG}_bench_${SFX}.json 2> $OUT/bench_${SFX}.err || exit 1
 echo "bench done"
 
-rocprofv3 --kernel-trace -d $OUT/trace_$SFX -- python3 bench.py --no-cpu-baseline $ARGS --steps 12 --warmup 3 > $OUT/trace_$SFX.log 2>&1 || exit 1
+# the same command as the bench line above (50 timed steps behind 10 warm-up steps); the statistics cover the timed steps only
+# (the last 5/6 of every kernel's launches), like bench.py's own HIP-event average
+rocprofv3 --kernel-trace -d $OUT/trace_$SFX -- python3 bench.py --no-cpu-baseline $ARGS --steps 50 --warmup 10 > $OUT/trace_$SFX.log 2>&1 || exit 1
 DB=$(find $OUT/trace_$SFX -name "*.db" | head -1)
-python3 tools/rocprof_summary.py stats $DB > $OUT/${TAG}_kernel_stats_${SFX}.csv
+python3 tools/rocprof_summary.py stats $DB 0.18 > $OUT/${TAG}_kernel_stats_${SFX}.csv
 python3 tools/rocprof_summary.py gaps $DB > $OUT/${TAG}_step_gaps_${SFX}.csv
 if [ "$4" == "full" ]; then python3 tools/rocprof_summary.py timeline $DB 8 > $OUT/${TAG}_step_timeline_${SFX}.csv; fi
 echo "trace done"

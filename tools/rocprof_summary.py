@@ -44,10 +44,14 @@ def kernels(db):
     return list(cur.execute("select name, start, end from kernels order by start"))
 
 
-def stats(db):
+def stats(db, skip_frac=0.0):
+    """Per-kernel statistics; skip_frac drops the first share of every kernel's launches (the warm-up steps of a bench run: the
+    clocks and caches of a fresh process settle over the first ~15 steps, bench.py's timed region starts behind its own warm-up)."""
     agg = collections.defaultdict(list)
     for name, s, e in kernels(db):
         agg[short(name)].append(e - s)
+    if skip_frac > 0.0:
+        agg = {k: v[int(len(v) * skip_frac) & ~1:] or v for k, v in agg.items()}      # (an even number: chained kernels launch in pairs)
     total = sum(sum(v) for v in agg.values())
     print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"')
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
@@ -150,7 +154,7 @@ def sq_derived(path):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
     elif mode == "gaps":
         gaps(sys.argv[2])
     elif mode == "timeline":

@@ -19,12 +19,13 @@ from oracle import features as ofeat
 from oracle import pace_oracle as po
 from dags_vae_search_amd import PaceVaeV3, LabeledGraph, optim as dopt
 from dags_vae_search_amd.train import train_batch
-cfg = po.PaceConfig(n=12, card=12)
+NV, NB = %(n)d, %(b)d
+cfg = po.PaceConfig(n=NV, card=NV)
 params = po.init_params(cfg, seed=5)
-m = PaceVaeV3(12, 12, 32, 8, 3, 64, 32, 32, 0.15)
+m = PaceVaeV3(NV, NV, 32, 8, 3, 64, 32, 32, 0.15)
 m.load_state_dict(params)
 m = m.to("cuda:0").train()
-graphs = ofeat.synthetic_dags(12, 12, 1000, seed=7)          # ragged: 1000 DAGs = 125 workgroups of 8
+graphs = ofeat.synthetic_dags(NV, NV, NB, seed=7, density_limit=0.2 if NV > 20 else 0.4)   # n = 12: ragged, 1000 DAGs = 125 workgroups of 8
 f = m.prepare_features([LabeledGraph(l, e) for l, e in graphs])
 m.seed(11)
 losses = m.loss_and_grad(f).clone()
@@ -45,12 +46,13 @@ print("VALUES", float(losses[0]), float(g0.norm()), float(g0.abs().max()), float
 """
 
 
-def run_child(split: bool, latent_kernels: bool = False, nw: int = 8):
+def run_child(split: bool, latent_kernels: bool = False, nw: int = 8, n: int = 12, batch: int = 1000):
     env = dict(os.environ)
     env["DVS_SPLIT_STACK"] = "1" if split else "0"
     env["DVS_LATENT_KERNELS"] = "1" if latent_kernels else "0"
     env["DVS_WAVES_PER_WG"] = str(nw)
-    out = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO, "n": n, "b": batch}], env=env, capture_output=True, text=True,
+                         timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
     vals = [float(x) for x in [ln for ln in out.stdout.splitlines() if ln.startswith("VALUES")][-1].split()[1:]]
@@ -71,3 +73,13 @@ def test_chained_and_split_launches_agree_bitwise():
     assert abs(v4[0] - v8[0]) <= 1e-6 * abs(v8[0])                  # loss: per-DAG values are identical, the sum order too
     assert abs(v4[1] - v8[1]) <= 1e-5 * v8[1] and abs(v4[2] - v8[2]) <= 1e-4 * v8[2]
     assert abs(v4[3] - v8[3]) <= 1e-4 * abs(v8[3])                  # the loss of the third train step
+
+
+def test_wide_path_token_local_chains_and_split_launches_agree_bitwise():
+    """The tiled path (n = 37: three tiles per DAG) launches its attention sublayers on their own, but the token-local backward
+    phases between two of them (a layer's q / k / v projections and the FFN of the layer below) travel as one chained launch
+    since round 3: against one launch per phase (DVS_SPLIT_STACK=1) losses, gradients, three train steps and the encoder means
+    must agree bit for bit.  600 DAGs: ragged against the 256 persistent workgroups (two DAGs in flight per workgroup in the
+    attention backward: first pass fills, last pass has nothing to fill)."""
+    (chained, _), (split, _) = run_child(False, n=37, batch=600), run_child(True, n=37, batch=600)
+    assert chained == split
